@@ -1,0 +1,760 @@
+/*
+ * h2y_api.hip -- the C-ABI shim declared in include/hdr2yuv_hip.h.
+ *
+ * Host side of the drop-in boundary: descriptor validation, the scalar setup
+ * the reference does in init_pic()/set_pic_clip() (common.cpp:172-327), device
+ * buffer ownership, and kernel launches.  No pixel is ever computed on the
+ * host: without a HIP device h2y_ctx_create() fails and nothing else works.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/hdr2yuv_hip.h"
+#include "h2y_kernels.h"
+#include "h2y_math.h"
+
+using namespace h2y;
+
+namespace {
+
+thread_local std::string g_err;
+
+struct clip_limits { /* clip_limits_t, hdr.h:345-356 */
+    uint32_t minCV, maxCV, minVR, maxVR, minVRC, maxVRC, Half;
+};
+
+/* set_pic_clip(), common.cpp:300-327 */
+clip_limits make_clip(int bit_depth, int full_range)
+{
+    clip_limits c;
+    c.minCV = 0;
+    c.maxCV = (1u << bit_depth) - 1;
+    c.Half = 1u << (bit_depth - 1);
+    if (!full_range) {
+        uint32_t D = 1u << (bit_depth - 8);
+        c.minVR = 16 * D;
+        c.maxVR = 219 * D + c.minVR; /* = 235*D, kept as the reference has it */
+        c.minVRC = c.minVR;
+        c.maxVRC = 224 * D + c.minVRC;
+    } else {
+        c.minVR = 0;
+        c.maxVR = c.maxCV;
+        c.minVRC = 0;
+        c.maxVRC = c.maxCV;
+    }
+    return c;
+}
+
+const int kMaxEvents = 64;
+const int kFirSubBatch = 8;
+
+} // namespace
+
+struct h2y_ctx {
+    int device = 0;
+    int n_cu = 0;
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    void *d_table = nullptr;
+    /* per-batch device arrays */
+    frame_io *d_frames = nullptr, *h_frames = nullptr;
+    size_t frames_cap = 0;
+    float *d_partial = nullptr;
+    size_t partial_cap = 0;
+    frame_stats *d_fstats = nullptr, *h_fstats = nullptr;
+    size_t fstats_cap = 0;
+    assumed_stats *d_assumed = nullptr, *h_assumed = nullptr; /* [2]: [0] batch, [1] redo */
+    uint16_t *d_tmp = nullptr;
+    size_t tmp_cap = 0;
+    /* staging for the host-buffer entry */
+    void *d_in = nullptr;
+    size_t in_cap = 0;
+    uint16_t *d_out = nullptr;
+    size_t out_cap = 0;
+    /* floor/ceiling of the last frame seen: the assumption for the next batch */
+    bool have_hint = false;
+    int hint_kind = -1;
+    int32_t hint_floor[3] = {0, 0, 0}, hint_ceil[3] = {0, 0, 0};
+    /* pending batch */
+    bool pending = false;
+    h2y_desc p_desc;
+    int p_n = 0;
+    bool p_check = false;
+    std::vector<frame_io> p_frames;
+    /* timing of the main kernels */
+    hipEvent_t ev[kMaxEvents][2];
+    int n_ev = 0;
+    float last_ms = 0.f;
+    int last_launches = 0;
+    std::string err;
+};
+
+namespace {
+
+int fail(h2y_ctx *ctx, int code, const char *fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, call)                                                                                  \
+    do {                                                                                                    \
+        hipError_t e_ = (call);                                                                             \
+        if (e_ != hipSuccess) return fail(ctx, H2Y_EHIP, "%s: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+template <typename T> int ensure(h2y_ctx *ctx, T *&p, size_t &cap, size_t need_bytes)
+{
+    if (cap >= need_bytes) return 0;
+    if (p) HIP_TRY(ctx, hipFree(p));
+    p = nullptr;
+    cap = 0;
+    void *q = nullptr;
+    hipError_t e = hipMalloc(&q, need_bytes);
+    if (e != hipSuccess) return fail(ctx, H2Y_ENOMEM, "hipMalloc(%zu): %s", need_bytes, hipGetErrorString(e));
+    p = static_cast<T *>(q);
+    cap = need_bytes;
+    return 0;
+}
+
+int in_kind_of(const h2y_desc *d)
+{
+    return d->in_sample_type == H2Y_SAMPLE_F32 ? H2Y_IN_F32 : d->in_sample_type == H2Y_SAMPLE_F16 ? H2Y_IN_F16 : H2Y_IN_U16;
+}
+size_t sample_bytes(const h2y_desc *d) { return d->in_sample_type == H2Y_SAMPLE_F32 ? 4 : 2; }
+
+/* hdr2yuv.cpp:803-808: the matrix_convert() target takes the input's depth
+ * when both pictures are U16, else the output's */
+int tmp_depth_of(const h2y_desc *d) { return d->in_sample_type == H2Y_SAMPLE_U16 ? d->src_bit_depth : d->dst_bit_depth; }
+
+/* Scalar setup for the kernels: everything matrix_convert()/convert()/
+ * write_yuv() derive from the picture attributes before their pixel loops. */
+void derive_params(const h2y_desc *d, pix_params *pp, bool stage_matrix_only)
+{
+    memset(pp, 0, sizeof *pp);
+    const int tmp_depth = tmp_depth_of(d);
+    const clip_limits tc = make_clip(tmp_depth, d->dst_full_range);
+    const clip_limits oc = make_clip(d->dst_bit_depth, d->dst_full_range);
+    pp->convert_transfer = d->src_transfer != d->dst_transfer; /* convert.cpp:930 */
+    /* convert.cpp:1123-1145 */
+    if (d->dst_full_range) {
+        pp->scale_mode = H2Y_SCALE_FULL;
+        pp->mulY = pp->mulC = (float)tc.maxCV;
+    } else if (d->dst_matrix == H2Y_MATRIX_GBR) {
+        pp->scale_mode = H2Y_SCALE_GBR;
+        pp->mulY = pp->mulC = (float)(int)tc.maxVR;
+        pp->addY = pp->addC = (float)(int)tc.minVR;
+    } else {
+        pp->scale_mode = H2Y_SCALE_YCC;
+        pp->mulY = (float)(int)tc.maxVR;
+        pp->addY = (float)(int)tc.minVR;
+        pp->mulC = (float)(int)tc.maxVRC;
+        pp->addC = (float)(int)tc.minVRC;
+    }
+    /* convert.cpp:1159-1198 */
+    if (d->dst_matrix == d->src_matrix && d->dst_primaries == d->src_primaries) pp->mode = H2Y_MODE_IDENTITY;
+    else if (d->dst_matrix == H2Y_MATRIX_YDZDX) pp->mode = H2Y_MODE_YDZDX;
+    else if (d->dst_matrix == H2Y_MATRIX_BT2020NC) {
+        pp->mode = H2Y_MODE_YCBCR;
+        pp->kr = 0.2627; pp->kg = 0.6780; pp->kb = 0.0593; pp->dcb = 1.8814; pp->dcr = 1.4746;
+    } else if (d->dst_matrix == H2Y_MATRIX_BT709) {
+        pp->mode = H2Y_MODE_YCBCR;
+        pp->kr = 0.2126; pp->kg = 0.7152; pp->kb = 0.0722; pp->dcb = 1.8556; pp->dcr = 1.5748;
+    } else {
+        pp->mode = H2Y_MODE_YPQRS; /* convert.cpp:913-925 */
+        if (d->dst_matrix == H2Y_MATRIX_YDZDX_Y100) { pp->P = -0.5f; pp->Q = 0.491722f; pp->RR = 0.5f; pp->S = -0.49495f; }
+        else { pp->P = -0.5f; pp->Q = 0.493393f; pp->RR = 0.5f; pp->S = -0.49602f; }
+    }
+    if (pp->mode == H2Y_MODE_YCBCR) {
+        pp->inv_dcb = 1.0 / pp->dcb;
+        pp->inv_dcr = 1.0 / pp->dcr;
+    }
+    pp->half_m1 = tc.Half - 1;
+    pp->maxCV = tc.maxCV;
+    pp->fir_max = (float)tc.maxCV;
+    if (stage_matrix_only) { /* identity clamp: values are already <= maxCV <= 65535 */
+        pp->down_shift = 0;
+        pp->full_range = 1;
+        pp->out_maxCV = 0xFFFFu;
+    } else {
+        pp->down_shift = tmp_depth - d->dst_bit_depth; /* tiff.cpp:394 */
+        pp->full_range = d->dst_full_range;
+        pp->ylo = oc.minVR; pp->yhi = oc.maxVR; pp->clo = oc.minVRC; pp->chi = oc.maxVRC;
+        pp->out_maxCV = oc.maxCV;
+    }
+}
+
+struct geom {
+    bool narrow;
+    uint32_t wq, wq_magic, tiles, chunks;
+};
+geom make_geom(const h2y_desc *d)
+{
+    geom g;
+    g.narrow = (d->width % 4) != 0;
+    g.wq = g.narrow ? (uint32_t)d->width : (uint32_t)d->width / 4;
+    g.wq_magic = (uint32_t)(0x100000000ull / g.wq);
+    if (g.wq == 1) g.wq_magic = 0xFFFFFFFFu;
+    g.tiles = g.wq * (uint32_t)((d->height + 1) / 2);
+    g.chunks = (g.tiles + H2Y_FUSED_THREADS - 1) / H2Y_FUSED_THREADS;
+    return g;
+}
+
+int grid_for(const h2y_ctx *ctx, uint64_t total_chunks)
+{
+    uint64_t g = (uint64_t)ctx->n_cu * 2; /* 2 x 512 threads per CU: LDS 51 KB + <=128 VGPR each */
+    if (g > total_chunks) g = total_chunks;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+int out_kind_of(const h2y_desc *d)
+{
+    if (d->dst_chroma_format_idc == H2Y_CHROMA_444) return H2Y_OUT_444;
+    return d->chroma_resampler_type == 0 ? H2Y_OUT_420BOX : H2Y_OUT_444TMP;
+}
+
+/* launch fused (+FIR) over frames [0,n) whose frame_io entries are in h_frames */
+int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, const assumed_stats *d_assumed,
+               bool check, int fstats_offset, bool time_it)
+{
+    pix_params pp;
+    derive_params(d, &pp, false);
+    const geom g = make_geom(d);
+    const int out_kind = out_kind_of(d);
+    const size_t npix = (size_t)d->width * d->height;
+    const int step = out_kind == H2Y_OUT_444TMP ? kFirSubBatch : n;
+    if (out_kind == H2Y_OUT_444TMP) {
+        int rc = ensure(ctx, ctx->d_tmp, ctx->tmp_cap, (size_t)kFirSubBatch * 2 * npix * sizeof(uint16_t));
+        if (rc) return rc;
+    }
+    for (int f0 = 0; f0 < n; f0 += step) {
+        const int nf = (n - f0 < step) ? n - f0 : step;
+        /* frame descriptors: host -> device (tiny) */
+        for (int i = 0; i < nf; i++) {
+            frame_io io = frames[f0 + i];
+            if (out_kind == H2Y_OUT_444TMP) {
+                io.tmp_cb = ctx->d_tmp + (size_t)i * 2 * npix;
+                io.tmp_cr = io.tmp_cb + npix;
+            }
+            ctx->h_frames[f0 + i] = io;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frames + f0, ctx->h_frames + f0, nf * sizeof(frame_io), hipMemcpyHostToDevice,
+                                    ctx->stream));
+        const int grid = grid_for(ctx, (uint64_t)g.chunks * nf);
+        int rc = ensure(ctx, ctx->d_partial, ctx->partial_cap, (size_t)nf * grid * 6 * sizeof(float));
+        if (rc) return rc;
+        fused_args a;
+        a.frames = ctx->d_frames + f0;
+        a.n_frames = nf;
+        a.width = d->width;
+        a.height = d->height;
+        a.wq = g.wq;
+        a.wq_magic = g.wq_magic;
+        a.tiles_per_frame = g.tiles;
+        a.chunks_per_frame = g.chunks;
+        a.table = ctx->d_table;
+        a.partial = ctx->d_partial;
+        a.assumed = d_assumed;
+        a.pp = pp;
+        const bool ev = time_it && ctx->n_ev < kMaxEvents;
+        if (ev) HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->n_ev][0], ctx->stream));
+        HIP_TRY(ctx, h2y_launch_fused(in_kind_of(d), out_kind, g.narrow, grid, ctx->stream, a));
+        if (ev) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->n_ev][1], ctx->stream));
+            ctx->n_ev++;
+        }
+        final_args fa;
+        fa.partial = ctx->d_partial;
+        fa.nblk = grid;
+        fa.out = ctx->d_fstats + fstats_offset + f0;
+        fa.is_u16 = d->in_sample_type == H2Y_SAMPLE_U16;
+        fa.src_bit_depth = d->src_bit_depth;
+        fa.check = check ? 1 : 0;
+        fa.assumed = d_assumed;
+        fa.publish = nullptr;
+        HIP_TRY(ctx, h2y_launch_stats_final(nf, ctx->stream, fa));
+        if (out_kind == H2Y_OUT_444TMP) {
+            for (int i = 0; i < nf; i++) {
+                fir_args fr;
+                fr.src_cb = ctx->h_frames[f0 + i].tmp_cb;
+                fr.src_cr = ctx->h_frames[f0 + i].tmp_cr;
+                fr.dst_cb = frames[f0 + i].out + npix;
+                fr.dst_cr = fr.dst_cb + (size_t)(d->width >> 1) * (d->height >> 1);
+                fr.width = d->width;
+                fr.height = d->height;
+                fr.fir_max = pp.fir_max;
+                fr.apply_yuv_clamp = 1;
+                fr.pp = pp;
+                HIP_TRY(ctx, h2y_launch_fir420(ctx->stream, fr));
+            }
+        }
+    }
+    return 0;
+}
+
+int reserve_batch(h2y_ctx *ctx, int n)
+{
+    if ((size_t)n > ctx->frames_cap) {
+        if (ctx->d_frames) HIP_TRY(ctx, hipFree(ctx->d_frames));
+        if (ctx->h_frames) HIP_TRY(ctx, hipHostFree(ctx->h_frames));
+        if (ctx->d_fstats) HIP_TRY(ctx, hipFree(ctx->d_fstats));
+        if (ctx->h_fstats) HIP_TRY(ctx, hipHostFree(ctx->h_fstats));
+        ctx->d_frames = nullptr; ctx->h_frames = nullptr; ctx->d_fstats = nullptr; ctx->h_fstats = nullptr;
+        ctx->frames_cap = 0;
+        size_t cap = (size_t)n < 64 ? 64 : (size_t)n;
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_frames, cap * sizeof(frame_io)));
+        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_frames, cap * sizeof(frame_io), hipHostMallocDefault));
+        /* +1: slot for the stats pre-pass / redo */
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_fstats, (cap + 1) * sizeof(frame_stats)));
+        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_fstats, (cap + 1) * sizeof(frame_stats), hipHostMallocDefault));
+        ctx->frames_cap = cap;
+    }
+    return 0;
+}
+
+/* pic_stats() of one frame on the device; result lands in d_fstats[slot] and,
+ * when publish != NULL, as the assumption for later kernels -- no host sync. */
+int run_stats(h2y_ctx *ctx, const h2y_desc *d, const void *const in[3], int slot, assumed_stats *publish)
+{
+    const size_t npix = (size_t)d->width * d->height;
+    int grid = ctx->n_cu * 4;
+    size_t need_blocks = (npix / 4 + H2Y_FUSED_THREADS - 1) / H2Y_FUSED_THREADS;
+    if ((size_t)grid > need_blocks) grid = need_blocks ? (int)need_blocks : 1;
+    int rc = ensure(ctx, ctx->d_partial, ctx->partial_cap, (size_t)grid * 6 * sizeof(float));
+    if (rc) return rc;
+    stats_args sa;
+    bool aligned = true;
+    for (int c = 0; c < 3; c++) {
+        sa.in[c] = in[c];
+        if (((uintptr_t)in[c]) & 15) aligned = false;
+    }
+    sa.npix = npix;
+    sa.vec_ok = aligned ? 1 : 0;
+    sa.partial = ctx->d_partial;
+    HIP_TRY(ctx, h2y_launch_stats(in_kind_of(d), grid, ctx->stream, sa));
+    final_args fa;
+    fa.partial = ctx->d_partial;
+    fa.nblk = grid;
+    fa.out = ctx->d_fstats + slot;
+    fa.is_u16 = d->in_sample_type == H2Y_SAMPLE_U16;
+    fa.src_bit_depth = d->src_bit_depth;
+    fa.check = 0;
+    fa.assumed = nullptr;
+    fa.publish = publish;
+    HIP_TRY(ctx, h2y_launch_stats_final(1, ctx->stream, fa));
+    return 0;
+}
+
+} // namespace
+
+extern "C" {
+
+int h2y_abi_version(void) { return H2Y_ABI_VERSION; }
+
+int h2y_desc_check(const h2y_desc *d, const char **why)
+{
+    const char *w = nullptr;
+    int rc = H2Y_OK;
+#define BAD(code, msg) do { rc = (code); w = (msg); goto done; } while (0)
+    if (!d) BAD(H2Y_EINVAL, "null descriptor");
+    if (d->width < 1 || d->width > 16384 || d->height < 1 || d->height > 16384) BAD(H2Y_EINVAL, "picture dimensions out of bounds");
+    if (d->in_sample_type != H2Y_SAMPLE_F32 && d->in_sample_type != H2Y_SAMPLE_F16 && d->in_sample_type != H2Y_SAMPLE_U16)
+        BAD(H2Y_EINVAL, "in_sample_type not recognized"); /* common.cpp:229-233 */
+    if (d->dst_bit_depth < 8 || d->dst_bit_depth > 16) BAD(H2Y_EINVAL, "dst_bit_depth must be 8..16");
+    if (d->in_sample_type == H2Y_SAMPLE_U16) {
+        if (d->src_bit_depth < 8 || d->src_bit_depth > 16) BAD(H2Y_EINVAL, "src_bit_depth must be 8..16 for U16 input");
+        if (d->dst_bit_depth > d->src_bit_depth) BAD(H2Y_EINVAL, "dst bitdepth > src bitdepth"); /* tiff.cpp:396-401 */
+    }
+    if (d->dst_chroma_format_idc != H2Y_CHROMA_420 && d->dst_chroma_format_idc != H2Y_CHROMA_444)
+        BAD(H2Y_EUNSUPPORTED, "dst_chroma_format_idc must be 1 (4:2:0) or 3 (4:4:4)");
+    if (d->dst_chroma_format_idc == H2Y_CHROMA_420) {
+        if ((d->width & 1) || (d->height & 1)) BAD(H2Y_EINVAL, "4:2:0 needs even width and height");
+        if (d->chroma_resampler_type == 0 && ((d->width & 3) || (d->height & 3)))
+            BAD(H2Y_EINVAL, "box resampler reads 4x4 tiles: width and height must be multiples of 4"); /* convert.cpp:100-140 */
+    }
+    if (d->src_transfer != d->dst_transfer && !(d->src_transfer == H2Y_TRANSFER_LINEAR && d->dst_transfer == H2Y_TRANSFER_PQ))
+        BAD(H2Y_EUNSUPPORTED, "only LINEAR(8) -> PQ(16) or equal transfer characteristics are on this path");
+    if (!(d->dst_matrix == d->src_matrix && d->dst_primaries == d->src_primaries)) {
+        switch (d->dst_matrix) {
+        case H2Y_MATRIX_YDZDX: case H2Y_MATRIX_BT2020NC: case H2Y_MATRIX_BT709:
+        case H2Y_MATRIX_YDZDX_Y100: case H2Y_MATRIX_YDZDX_Y500: break;
+        default: BAD(H2Y_EUNSUPPORTED, "can't determine color difference to use"); /* convert.cpp:1195-1197 */
+        }
+    }
+    if (d->stats_override)
+        for (int c = 0; c < 3; c++)
+            if (d->src_transfer != d->dst_transfer && d->ceiling[c] == d->floor[c])
+                BAD(H2Y_EINVAL, "stats override with ceiling == floor (division by zero range)");
+done:
+#undef BAD
+    if (why) *why = w ? w : "ok";
+    return rc;
+}
+
+size_t h2y_frame_bytes(const h2y_desc *d)
+{
+    if (!d || d->width < 1 || d->height < 1) return 0;
+    size_t n = (size_t)d->width * d->height;
+    size_t nc = d->dst_chroma_format_idc == H2Y_CHROMA_420 ? (size_t)(d->width >> 1) * (d->height >> 1) : n;
+    return (n + 2 * nc) * sizeof(uint16_t);
+}
+
+size_t h2y_plane_bytes(const h2y_desc *d)
+{
+    if (!d || d->width < 1 || d->height < 1) return 0;
+    return (size_t)d->width * d->height * sample_bytes(d);
+}
+
+const char *h2y_last_error(const h2y_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int h2y_ctx_create(int device, h2y_ctx **out)
+{
+    if (!out) return fail(nullptr, H2Y_EINVAL, "null out pointer");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1)
+        return fail(nullptr, H2Y_EHIP, "no HIP device (%s): this library has no CPU path", hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(nullptr, H2Y_EINVAL, "device %d out of range (have %d)", device, ndev);
+    h2y_ctx *ctx = new (std::nothrow) h2y_ctx();
+    if (!ctx) return fail(nullptr, H2Y_ENOMEM, "out of host memory");
+    ctx->device = device;
+    HIP_TRY(ctx, hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(ctx, hipGetDeviceProperties(&prop, device));
+    ctx->n_cu = prop.multiProcessorCount;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+    for (int i = 0; i < kMaxEvents; i++) {
+        HIP_TRY(ctx, hipEventCreate(&ctx->ev[i][0]));
+        HIP_TRY(ctx, hipEventCreate(&ctx->ev[i][1]));
+    }
+    /* PQ fast-tier table: built on the host once, lives in HBM, staged to LDS per block */
+    {
+        std::vector<pq_recA> A(H2Y_PQ_NSEG);
+        std::vector<pq_recB> B(H2Y_PQ_NSEG);
+        pq_build_table(A.data(), B.data());
+        HIP_TRY(ctx, hipMalloc(&ctx->d_table, H2Y_PQ_TABLE_BYTES));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_table, A.data(), H2Y_PQ_NSEG * sizeof(pq_recA), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy((char *)ctx->d_table + H2Y_PQ_NSEG * sizeof(pq_recA), B.data(), H2Y_PQ_NSEG * sizeof(pq_recB),
+                               hipMemcpyHostToDevice));
+    }
+    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_assumed, 2 * sizeof(assumed_stats)));
+    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_assumed, 2 * sizeof(assumed_stats), hipHostMallocDefault));
+    int rc = reserve_batch(ctx, 64);
+    if (rc) { h2y_ctx_destroy(ctx); return rc; }
+    *out = ctx;
+    return H2Y_OK;
+}
+
+void h2y_ctx_destroy(h2y_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < kMaxEvents; i++) {
+        if (ctx->ev[i][0]) (void)hipEventDestroy(ctx->ev[i][0]);
+        if (ctx->ev[i][1]) (void)hipEventDestroy(ctx->ev[i][1]);
+    }
+    (void)hipFree(ctx->d_table);
+    (void)hipFree(ctx->d_frames);
+    (void)hipHostFree(ctx->h_frames);
+    (void)hipFree(ctx->d_partial);
+    (void)hipFree(ctx->d_fstats);
+    (void)hipHostFree(ctx->h_fstats);
+    (void)hipFree(ctx->d_assumed);
+    (void)hipHostFree(ctx->h_assumed);
+    (void)hipFree(ctx->d_tmp);
+    (void)hipFree(ctx->d_in);
+    (void)hipFree(ctx->d_out);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int h2y_ctx_set_stream(h2y_ctx *ctx, void *hip_stream)
+{
+    if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
+    if (ctx->pending) return fail(ctx, H2Y_EINVAL, "a batch is pending: call h2y_batch_finish first");
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return H2Y_OK;
+}
+
+int h2y_convert_batch_enqueue(h2y_ctx *ctx, const h2y_desc *d, int n_frames, const void *const *d_in, uint16_t *const *d_out)
+{
+    if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
+    if (ctx->pending) return fail(ctx, H2Y_EINVAL, "a batch is already pending: call h2y_batch_finish first");
+    const char *why;
+    int rc = h2y_desc_check(d, &why);
+    if (rc) return fail(ctx, rc, "descriptor: %s", why);
+    if (n_frames < 1 || !d_in || !d_out) return fail(ctx, H2Y_EINVAL, "n_frames < 1 or null pointer arrays");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    rc = reserve_batch(ctx, n_frames);
+    if (rc) return rc;
+    ctx->p_frames.resize(n_frames);
+    for (int f = 0; f < n_frames; f++) {
+        frame_io io;
+        for (int c = 0; c < 3; c++) {
+            io.in[c] = d_in[f * 3 + c];
+            if (!io.in[c] || ((uintptr_t)io.in[c] & 15)) return fail(ctx, H2Y_EINVAL, "input plane %d of frame %d is null or not 16-byte aligned", c, f);
+        }
+        io.out = d_out[f];
+        if (!io.out || ((uintptr_t)io.out & 15)) return fail(ctx, H2Y_EINVAL, "output of frame %d is null or not 16-byte aligned", f);
+        io.tmp_cb = io.tmp_cr = nullptr;
+        ctx->p_frames[f] = io;
+    }
+    ctx->n_ev = 0;
+    const bool needs_stats = d->src_transfer != d->dst_transfer; /* convert.cpp:930-940: stats are only read then */
+    bool check = false;
+    assumed_stats *as = ctx->h_assumed;
+    if (!needs_stats || d->stats_override) {
+        for (int c = 0; c < 3; c++) {
+            as->floor_[c] = d->stats_override ? d->floor[c] : 0;
+            as->ceil_[c] = d->stats_override ? d->ceiling[c] : 1;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_assumed, as, sizeof *as, hipMemcpyHostToDevice, ctx->stream));
+    } else if (ctx->have_hint && ctx->hint_kind == d->in_sample_type) {
+        /* assume this batch looks like the last frame we saw; verified below */
+        for (int c = 0; c < 3; c++) {
+            as->floor_[c] = ctx->hint_floor[c];
+            as->ceil_[c] = ctx->hint_ceil[c];
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_assumed, as, sizeof *as, hipMemcpyHostToDevice, ctx->stream));
+        check = true;
+    } else {
+        /* no history: measure frame 0 (pic_stats pre-pass) and assume the rest match it */
+        rc = run_stats(ctx, d, ctx->p_frames[0].in, (int)ctx->frames_cap, ctx->d_assumed);
+        if (rc) return rc;
+        check = true;
+    }
+    rc = run_frames(ctx, d, ctx->p_frames.data(), n_frames, ctx->d_assumed, check, 0, true);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_fstats, ctx->d_fstats, n_frames * sizeof(frame_stats), hipMemcpyDeviceToHost, ctx->stream));
+    ctx->pending = true;
+    ctx->p_desc = *d;
+    ctx->p_n = n_frames;
+    ctx->p_check = check;
+    return H2Y_OK;
+}
+
+int h2y_batch_finish(h2y_ctx *ctx, int *n_redone)
+{
+    if (n_redone) *n_redone = 0;
+    if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
+    if (!ctx->pending) return H2Y_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->pending = false;
+    float ms = 0.f;
+    for (int i = 0; i < ctx->n_ev; i++) {
+        float t = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&t, ctx->ev[i][0], ctx->ev[i][1]));
+        ms += t;
+    }
+    ctx->last_ms = ms;
+    ctx->last_launches = ctx->n_ev;
+    int redone = 0;
+    const h2y_desc *d = &ctx->p_desc;
+    if (ctx->p_check) {
+        for (int f = 0; f < ctx->p_n; f++) {
+            if (!ctx->h_fstats[f].mismatch) continue;
+            /* the assumption was wrong for this frame: its true floor/ceiling are now
+             * known (the fused kernel measured them), so run it again with those */
+            assumed_stats *as = ctx->h_assumed + 1;
+            for (int c = 0; c < 3; c++) {
+                as->floor_[c] = ctx->h_fstats[f].floor_[c];
+                as->ceil_[c] = ctx->h_fstats[f].ceil_[c];
+            }
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->d_assumed + 1, as, sizeof *as, hipMemcpyHostToDevice, ctx->stream));
+            int rc = run_frames(ctx, d, &ctx->p_frames[f], 1, ctx->d_assumed + 1, false, (int)ctx->frames_cap, false);
+            if (rc) return rc;
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            redone++;
+        }
+    }
+    if (d->src_transfer != d->dst_transfer && !d->stats_override) {
+        const frame_stats &last = ctx->h_fstats[ctx->p_n - 1];
+        for (int c = 0; c < 3; c++) {
+            ctx->hint_floor[c] = last.floor_[c];
+            ctx->hint_ceil[c] = last.ceil_[c];
+        }
+        ctx->have_hint = true;
+        ctx->hint_kind = d->in_sample_type;
+    }
+    if (n_redone) *n_redone = redone;
+    return H2Y_OK;
+}
+
+int h2y_convert_batch(h2y_ctx *ctx, const h2y_desc *d, int n_frames, const void *const *d_in, uint16_t *const *d_out)
+{
+    int rc = h2y_convert_batch_enqueue(ctx, d, n_frames, d_in, d_out);
+    if (rc) return rc;
+    return h2y_batch_finish(ctx, nullptr);
+}
+
+int h2y_convert_frame(h2y_ctx *ctx, const h2y_desc *d, const void *const in_planes[3], uint16_t *out_yuv)
+{
+    if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
+    if (ctx->pending) return fail(ctx, H2Y_EINVAL, "a batch is pending: call h2y_batch_finish first");
+    const char *why;
+    int rc = h2y_desc_check(d, &why);
+    if (rc) return fail(ctx, rc, "descriptor: %s", why);
+    if (!in_planes || !in_planes[0] || !in_planes[1] || !in_planes[2] || !out_yuv) return fail(ctx, H2Y_EINVAL, "null buffer");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t pb = h2y_plane_bytes(d), pb_al = (pb + 255) & ~(size_t)255, ob = h2y_frame_bytes(d);
+    rc = ensure(ctx, ctx->d_in, ctx->in_cap, 3 * pb_al);
+    if (rc) return rc;
+    rc = ensure(ctx, ctx->d_out, ctx->out_cap, ob);
+    if (rc) return rc;
+    frame_io io;
+    for (int c = 0; c < 3; c++) {
+        io.in[c] = (char *)ctx->d_in + c * pb_al;
+        HIP_TRY(ctx, hipMemcpyAsync((void *)io.in[c], in_planes[c], pb, hipMemcpyHostToDevice, ctx->stream));
+    }
+    io.out = ctx->d_out;
+    io.tmp_cb = io.tmp_cr = nullptr;
+    /* the reference's order: pic_stats first, then the pixel loops with its result */
+    const bool needs_stats = d->src_transfer != d->dst_transfer;
+    if (needs_stats && !d->stats_override) {
+        rc = run_stats(ctx, d, io.in, (int)ctx->frames_cap, ctx->d_assumed);
+        if (rc) return rc;
+    } else {
+        assumed_stats *as = ctx->h_assumed;
+        for (int c = 0; c < 3; c++) {
+            as->floor_[c] = d->stats_override ? d->floor[c] : 0;
+            as->ceil_[c] = d->stats_override ? d->ceiling[c] : 1;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_assumed, as, sizeof *as, hipMemcpyHostToDevice, ctx->stream));
+    }
+    ctx->n_ev = 0;
+    rc = run_frames(ctx, d, &io, 1, ctx->d_assumed, false, 0, true);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(out_yuv, ctx->d_out, ob, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    for (int i = 0; i < ctx->n_ev; i++) {
+        float t = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&t, ctx->ev[i][0], ctx->ev[i][1]));
+        ms += t;
+    }
+    ctx->last_ms = ms;
+    ctx->last_launches = ctx->n_ev;
+    return H2Y_OK;
+}
+
+int h2y_pic_stats(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3], float fminmax[6], int32_t floor_ceiling[6])
+{
+    if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
+    if (ctx->pending) return fail(ctx, H2Y_EINVAL, "a batch is pending");
+    const char *why;
+    int rc = h2y_desc_check(d, &why);
+    if (rc) return fail(ctx, rc, "descriptor: %s", why);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    rc = run_stats(ctx, d, d_in, (int)ctx->frames_cap, nullptr);
+    if (rc) return rc;
+    frame_stats *hs = ctx->h_fstats + ctx->frames_cap;
+    HIP_TRY(ctx, hipMemcpyAsync(hs, ctx->d_fstats + ctx->frames_cap, sizeof(frame_stats), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 6; i++) fminmax[i] = hs->mm[i];
+    for (int c = 0; c < 3; c++) {
+        floor_ceiling[2 * c] = hs->floor_[c];
+        floor_ceiling[2 * c + 1] = hs->ceil_[c];
+    }
+    return H2Y_OK;
+}
+
+int h2y_matrix_convert(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3], uint16_t *const d_out444[3])
+{
+    if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
+    if (ctx->pending) return fail(ctx, H2Y_EINVAL, "a batch is pending");
+    const char *why;
+    int rc = h2y_desc_check(d, &why);
+    if (rc) return fail(ctx, rc, "descriptor: %s", why);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    assumed_stats *as = ctx->h_assumed;
+    for (int c = 0; c < 3; c++) {
+        as->floor_[c] = d->floor[c];
+        as->ceil_[c] = d->ceiling[c];
+    }
+    if (d->src_transfer != d->dst_transfer)
+        for (int c = 0; c < 3; c++)
+            if (d->floor[c] == d->ceiling[c]) return fail(ctx, H2Y_EINVAL, "floor == ceiling for plane %d", c);
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_assumed, as, sizeof *as, hipMemcpyHostToDevice, ctx->stream));
+    pix_params pp;
+    derive_params(d, &pp, true);
+    const geom g = make_geom(d);
+    frame_io io;
+    for (int c = 0; c < 3; c++) io.in[c] = d_in[c];
+    io.out = d_out444[0];
+    io.tmp_cb = d_out444[1];
+    io.tmp_cr = d_out444[2];
+    ctx->h_frames[0] = io;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frames, ctx->h_frames, sizeof(frame_io), hipMemcpyHostToDevice, ctx->stream));
+    const int grid = grid_for(ctx, g.chunks);
+    rc = ensure(ctx, ctx->d_partial, ctx->partial_cap, (size_t)grid * 6 * sizeof(float));
+    if (rc) return rc;
+    fused_args a;
+    a.frames = ctx->d_frames;
+    a.n_frames = 1;
+    a.width = d->width;
+    a.height = d->height;
+    a.wq = g.wq;
+    a.wq_magic = g.wq_magic;
+    a.tiles_per_frame = g.tiles;
+    a.chunks_per_frame = g.chunks;
+    a.table = ctx->d_table;
+    a.partial = ctx->d_partial;
+    a.assumed = ctx->d_assumed;
+    a.pp = pp;
+    HIP_TRY(ctx, h2y_launch_fused(in_kind_of(d), H2Y_OUT_444TMP, g.narrow, grid, ctx->stream, a));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return H2Y_OK;
+}
+
+int h2y_subsample_420(h2y_ctx *ctx, int width, int height, int bit_depth, int chroma_resampler_type, const uint16_t *d_src,
+                      uint16_t *d_dst)
+{
+    if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
+    if (ctx->pending) return fail(ctx, H2Y_EINVAL, "a batch is pending");
+    if (width < 2 || height < 2 || (width & 1) || (height & 1) || bit_depth < 8 || bit_depth > 16 || !d_src || !d_dst)
+        return fail(ctx, H2Y_EINVAL, "bad subsample arguments");
+    if (chroma_resampler_type == 0 && ((width & 3) || (height & 3))) return fail(ctx, H2Y_EINVAL, "box needs multiples of 4");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (chroma_resampler_type == 0) HIP_TRY(ctx, h2y_launch_box420(ctx->stream, d_src, d_dst, width, height));
+    else {
+        fir_args fr;
+        memset(&fr, 0, sizeof fr);
+        fr.src_cb = d_src;
+        fr.src_cr = nullptr;
+        fr.dst_cb = d_dst;
+        fr.dst_cr = nullptr;
+        fr.width = width;
+        fr.height = height;
+        fr.fir_max = (float)((1u << bit_depth) - 1);
+        fr.apply_yuv_clamp = 0;
+        HIP_TRY(ctx, h2y_launch_fir420(ctx->stream, fr));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return H2Y_OK;
+}
+
+int h2y_last_kernel_ms(const h2y_ctx *ctx, float *ms, int *launches)
+{
+    if (!ctx) return H2Y_EINVAL;
+    if (ms) *ms = ctx->last_ms;
+    if (launches) *launches = ctx->last_launches;
+    return H2Y_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,87 @@
+/* h2y_kernels.h -- argument blocks and launch entry points shared by
+ * h2y_kernels.hip (device code) and h2y_api.hip (the C-ABI shim). */
+#ifndef H2Y_KERNELS_H
+#define H2Y_KERNELS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "h2y_math.h"
+
+#define H2Y_FUSED_THREADS 512
+
+enum { H2Y_IN_F32 = 0, H2Y_IN_F16 = 1, H2Y_IN_U16 = 2 };
+enum { H2Y_OUT_420BOX = 0, H2Y_OUT_444 = 1, H2Y_OUT_444TMP = 2 };
+
+/* one frame's buffers (device pointers) */
+struct frame_io {
+    const void *in[3]; /* planes G,B,R (convert.cpp:980-982) */
+    uint16_t *out;     /* .yuv frame: Y | Cb | Cr */
+    uint16_t *tmp_cb;  /* H2Y_OUT_444TMP only: 4:4:4 matrix_convert output */
+    uint16_t *tmp_cr;
+};
+
+/* what k_stats_final leaves per frame */
+struct frame_stats {
+    float mm[6];       /* min0,max0,min1,max1,min2,max2 */
+    int32_t floor_[3]; /* pic_stats estimated_floor   */
+    int32_t ceil_[3];  /* pic_stats estimated_ceiling */
+    int32_t mismatch;  /* assumed != measured         */
+    int32_t pad;
+};
+
+/* estimated_floor/ceiling the pixel kernels normalise with (convert.cpp:939-940).
+ * Lives in device memory so that a stats pre-pass can hand it to the next
+ * kernel without a host round trip. */
+struct assumed_stats {
+    int32_t floor_[3];
+    int32_t ceil_[3];
+};
+
+struct fused_args {
+    const frame_io *frames; /* device array, n_frames entries */
+    int n_frames;
+    uint32_t width, height;
+    uint32_t wq;              /* width/4 (k_fused) or width (k_fused_narrow) */
+    uint32_t wq_magic;        /* floor(2^32 / wq) */
+    uint32_t tiles_per_frame; /* thread-tiles per frame */
+    uint32_t chunks_per_frame;
+    const void *table;        /* pq_recA[NSEG] then pq_recB[NSEG] */
+    float *partial;           /* [n_frames][grid][6] */
+    const assumed_stats *assumed;
+    h2y::pix_params pp;       /* offset/range/norm_identity are filled in-kernel from *assumed */
+};
+
+struct stats_args {
+    const void *in[3];
+    size_t npix;
+    int vec_ok;     /* planes 16-byte aligned and npix % 4 == 0 handled by tail loop */
+    float *partial; /* [grid][6] */
+};
+
+struct final_args {
+    const float *partial; /* [n_frames][nblk][6] */
+    int nblk;
+    frame_stats *out; /* [n_frames] */
+    int is_u16, src_bit_depth;
+    int check;                     /* compare against *assumed, set frame_stats.mismatch */
+    const assumed_stats *assumed;  /* may be NULL when check == 0 */
+    assumed_stats *publish;        /* not NULL: frame 0's floor/ceiling are written here */
+};
+
+struct fir_args {
+    const uint16_t *src_cb, *src_cr; /* 4:4:4 planes; src_cr may be NULL (one plane) */
+    uint16_t *dst_cb, *dst_cr;
+    int width, height;
+    float fir_max;       /* (float)clip->maxCV of the tmp picture, convert.cpp:314 */
+    int apply_yuv_clamp; /* 1: follow with write_yuv's shift + range clamp */
+    h2y::pix_params pp;
+};
+
+hipError_t h2y_launch_fused(int in_kind, int out_kind, bool narrow, int grid, hipStream_t st, const fused_args &a);
+hipError_t h2y_launch_stats(int in_kind, int grid, hipStream_t st, const stats_args &a);
+hipError_t h2y_launch_stats_final(int n_frames, hipStream_t st, const final_args &a);
+hipError_t h2y_launch_fir420(hipStream_t st, const fir_args &a);
+hipError_t h2y_launch_box420(hipStream_t st, const uint16_t *src, uint16_t *dst, int W, int H);
+
+#endif

@@ -1,0 +1,570 @@
+/*
+ * h2y_kernels.hip -- gfx950 kernels of the convert path.
+ *
+ *   k_stats        pic_stats()            common.cpp:66-139   (pre-pass form)
+ *   k_fused        matrix_convert()       convert.cpp:879-1221
+ *                  + convert() box / 4:4:4 convert.cpp:802-859 (+ :91-172)
+ *                  + write_yuv() clamp     tiff.cpp:457-550
+ *                  + pic_stats() min/max of the same samples, as a by-product
+ *   k_fir420       Subsample444to420_FIR  convert.cpp:261-383 + write_yuv clamp
+ *   k_box420       Subsample444to420_box  convert.cpp:91-172 (stage entry only)
+ *   k_stats_final  (int) floor/ceiling    common.cpp:135-136, and the check of
+ *                  the values k_fused assumed against the ones it measured
+ *
+ * The path is HBM-bound elementwise work: no MFMA.  Layout in HBM is the
+ * reference's: three planar row-major planes in (G,B,R) order, stride = width;
+ * output is one .yuv frame (Y plane, Cb plane, Cr plane, little-endian u16).
+ *
+ * Built with -ffp-contract=off: the reference's bytes depend on products and
+ * sums being rounded separately; fma() appears only where
+ * h2y_math.h asks for it by name.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "h2y_math.h"
+#include "h2y_kernels.h"
+
+using namespace h2y;
+
+#define WAVE 64
+
+/* ---- wave reductions (DPP via __shfl_xor on 64 lanes) ------------------- */
+__device__ __forceinline__ float wave_min(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+
+/* pic_stats update, common.cpp:126-127: "s < min ? s : min" -- a NaN never
+ * wins, which fminf/fmaxf reproduce (they return the non-NaN operand). */
+struct mm6 {
+    float lo[3], hi[3];
+    __device__ __forceinline__ void reset()
+    {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            lo[c] = 3.402823466e+38f; /* numeric_limits<float>::max(), common.cpp:118 */
+            hi[c] = 1.175494351e-38f; /* numeric_limits<float>::min(), common.cpp:119 */
+        }
+    }
+    __device__ __forceinline__ void add(int c, float s)
+    {
+        lo[c] = fminf(lo[c], s);
+        hi[c] = fmaxf(hi[c], s);
+    }
+};
+
+/* Block-wide reduce of a thread's mm6 and one plain store of the six floats
+ * by thread 0.  All threads of the block must call it. */
+template <int NWAVES>
+__device__ __forceinline__ void block_store_mm(mm6 &m, float *smem /* NWAVES*6 */, float *dst)
+{
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float a = wave_min(m.lo[c]), b = wave_max(m.hi[c]);
+        if (lane == 0) {
+            smem[wave * 6 + 2 * c] = a;
+            smem[wave * 6 + 2 * c + 1] = b;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = smem[threadIdx.x];
+        const bool is_max = threadIdx.x & 1;
+        for (int w = 1; w < NWAVES; w++) {
+            float o = smem[w * 6 + threadIdx.x];
+            v = is_max ? fmaxf(v, o) : fminf(v, o);
+        }
+        dst[threadIdx.x] = v;
+    }
+    __syncthreads();
+}
+
+/* ---- sample loads ------------------------------------------------------- */
+template <int KIND> struct in_traits;
+template <> struct in_traits<H2Y_IN_F32> {
+    typedef float T;
+    static __device__ __forceinline__ void load4(const void *p, size_t i, float v[4])
+    {
+        float4 q = *reinterpret_cast<const float4 *>(static_cast<const float *>(p) + i);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    }
+    static __device__ __forceinline__ float load1(const void *p, size_t i) { return static_cast<const float *>(p)[i]; }
+};
+template <> struct in_traits<H2Y_IN_F16> {
+    typedef _Float16 T;
+    static __device__ __forceinline__ void load4(const void *p, size_t i, float v[4])
+    {
+        /* exr.cpp:233-235: half widened to float, exact */
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        h4 q = *reinterpret_cast<const h4 *>(static_cast<const _Float16 *>(p) + i);
+        v[0] = (float)q.x; v[1] = (float)q.y; v[2] = (float)q.z; v[3] = (float)q.w;
+    }
+    static __device__ __forceinline__ float load1(const void *p, size_t i) { return (float)static_cast<const _Float16 *>(p)[i]; }
+};
+template <> struct in_traits<H2Y_IN_U16> {
+    typedef uint16_t T;
+    static __device__ __forceinline__ void load4(const void *p, size_t i, float v[4])
+    {
+        /* convert.cpp:989-994: (float) of the unsigned short */
+        uint2 q = *reinterpret_cast<const uint2 *>(static_cast<const uint16_t *>(p) + i);
+        v[0] = (float)(q.x & 0xFFFFu); v[1] = (float)(q.x >> 16);
+        v[2] = (float)(q.y & 0xFFFFu); v[3] = (float)(q.y >> 16);
+    }
+    static __device__ __forceinline__ float load1(const void *p, size_t i) { return (float)static_cast<const uint16_t *>(p)[i]; }
+};
+
+/* ---- one pixel: normalise -> PQ -> scale -> matrix ---------------------- */
+__device__ __forceinline__ float pq_sample(float x, const pq_recA *sA, const pq_recB *sB)
+{
+    bool slow;
+    float v = pq_fast(x, sA, sB, &slow);
+    if (__builtin_expect(slow, 0)) v = pq_slow(x);
+    return v;
+}
+
+__device__ __forceinline__ void pixel(const pix_params &pp, const pq_recA *sA, const pq_recB *sB, float G, float B,
+                                      float R, uint32_t &Y, uint32_t &Cb, uint32_t &Cr)
+{
+    if (pp.convert_transfer) {
+        if (!pp.norm_identity) {
+            /* convert.cpp:1017-1019, binary32 subtract and IEEE divide */
+            G = (G - pp.offset[0]) / pp.range[0];
+            B = (B - pp.offset[1]) / pp.range[1];
+            R = (R - pp.offset[2]) / pp.range[2];
+        }
+        G = pq_sample(G, sA, sB);
+        B = pq_sample(B, sA, sB);
+        R = pq_sample(R, sA, sB);
+        G = pix_scale(G, pp.mulY, pp.addY, pp.scale_mode);
+        B = pix_scale(B, pp.mulC, pp.addC, pp.scale_mode);
+        R = pix_scale(R, pp.mulC, pp.addC, pp.scale_mode);
+    }
+    pix_matrix(pp, G, B, R, Y, Cb, Cr);
+}
+
+/* convert.cpp:939-940: range = ceiling - floor (int), offset = floor, as float */
+__device__ __forceinline__ pix_params with_assumed(const pix_params &in, const assumed_stats *as)
+{
+    pix_params pp = in;
+    bool ident = true;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const int fl = as->floor_[c], ce = as->ceil_[c];
+        pp.offset[c] = (float)fl;
+        pp.range[c] = (float)(ce - fl);
+        ident = ident && fl == 0 && (ce - fl) == 1;
+    }
+    pp.norm_identity = ident ? 1 : 0;
+    return pp;
+}
+
+/* unsigned divide by a launch constant: q = n / d via a 32-bit reciprocal */
+__device__ __forceinline__ uint32_t udiv_magic(uint32_t n, uint32_t d, uint32_t magic, uint32_t &rem)
+{
+    uint32_t q = __umulhi(n, magic);
+    uint32_t r = n - q * d;
+    if (r >= d) {
+        q++;
+        r -= d;
+    }
+    rem = r;
+    return q;
+}
+
+/*
+ * k_fused: one thread = 4 columns x 2 rows of one frame.
+ *
+ * A chunk is H2Y_FUSED_THREADS consecutive thread-tiles of ONE frame (chunks
+ * never straddle frames); global chunk g belongs to block g % gridDim.x, so a
+ * block walks the frames in order and all its threads are always in the same
+ * frame.  After its last chunk of a frame the block reduces the min/max its
+ * threads saw and stores six floats to partial[frame][block] -- every
+ * (frame, block) slot is written exactly once per launch, no atomics, no
+ * initialisation.
+ *
+ * OUT_KIND:
+ *   H2Y_OUT_420BOX  Y final; Cb/Cr = truncating mean of the thread's own two
+ *                   2x2 blocks (convert.cpp:157-160), final
+ *   H2Y_OUT_444     Y, Cb, Cr final, full resolution
+ *   H2Y_OUT_444TMP  Y final; Cb/Cr = matrix_convert() output (NOT yet
+ *                   range-clamped) into scratch planes for k_fir420
+ */
+template <int IN_KIND, int OUT_KIND>
+__global__ __launch_bounds__(H2Y_FUSED_THREADS) void k_fused(fused_args a)
+{
+    __shared__ pq_recA sA[H2Y_PQ_NSEG];
+    __shared__ pq_recB sB[H2Y_PQ_NSEG];
+    __shared__ float s_red[(H2Y_FUSED_THREADS / WAVE) * 6];
+
+    if (a.pp.convert_transfer) {
+        const uint4 *gA = reinterpret_cast<const uint4 *>(a.table);
+        const uint4 *gB = gA + H2Y_PQ_NSEG;
+        uint4 *lA = reinterpret_cast<uint4 *>(sA), *lB = reinterpret_cast<uint4 *>(sB);
+        for (int i = threadIdx.x; i < H2Y_PQ_NSEG; i += H2Y_FUSED_THREADS) {
+            lA[i] = gA[i];
+            lB[i] = gB[i];
+        }
+    }
+    __syncthreads();
+
+    typedef in_traits<IN_KIND> IN;
+    const pix_params pp = with_assumed(a.pp, a.assumed);
+    const uint32_t W = a.width, H = a.height, WQ = a.wq;
+    const size_t npix = (size_t)W * H;
+    const uint32_t G = gridDim.x;
+
+    for (int f = 0; f < a.n_frames; f++) {
+        const frame_io io = a.frames[f];
+        mm6 mm;
+        mm.reset();
+        /* first chunk of frame f owned by this block */
+        const uint32_t gbase = (uint32_t)(((uint64_t)f * a.chunks_per_frame) % G);
+        uint32_t k = (blockIdx.x + G - gbase) % G;
+        for (; k < a.chunks_per_frame; k += G) {
+            const uint32_t tt = k * H2Y_FUSED_THREADS + threadIdx.x;
+            if (tt >= a.tiles_per_frame) continue;
+            uint32_t cg;
+            const uint32_t rp = udiv_magic(tt, WQ, a.wq_magic, cg);
+            const uint32_t x = cg * 4, y = rp * 2;
+            const bool row1 = (y + 1) < H;
+            const size_t i0 = (size_t)y * W + x, i1 = row1 ? i0 + W : i0;
+
+            float g0[4], b0[4], r0[4], g1[4], b1[4], r1[4];
+            IN::load4(io.in[0], i0, g0);
+            IN::load4(io.in[1], i0, b0);
+            IN::load4(io.in[2], i0, r0);
+            IN::load4(io.in[0], i1, g1);
+            IN::load4(io.in[1], i1, b1);
+            IN::load4(io.in[2], i1, r1);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                mm.add(0, g0[j]); mm.add(1, b0[j]); mm.add(2, r0[j]);
+                mm.add(0, g1[j]); mm.add(1, b1[j]); mm.add(2, r1[j]);
+            }
+
+            uint32_t Y0[4], Y1[4], Cb0[4], Cb1[4], Cr0[4], Cr1[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                pixel(pp, sA, sB, g0[j], b0[j], r0[j], Y0[j], Cb0[j], Cr0[j]);
+                pixel(pp, sA, sB, g1[j], b1[j], r1[j], Y1[j], Cb1[j], Cr1[j]);
+            }
+
+            uint16_t *Yp = io.out;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                Y0[j] = pix_yuv_clamp(pp, Y0[j], false);
+                Y1[j] = pix_yuv_clamp(pp, Y1[j], false);
+            }
+            *reinterpret_cast<uint2 *>(Yp + i0) = make_uint2(Y0[0] | (Y0[1] << 16), Y0[2] | (Y0[3] << 16));
+            if (row1) *reinterpret_cast<uint2 *>(Yp + i1) = make_uint2(Y1[0] | (Y1[1] << 16), Y1[2] | (Y1[3] << 16));
+
+            if (OUT_KIND == H2Y_OUT_420BOX) {
+                /* convert.cpp:157-160: (a+b+c+d)/4, unsigned truncation */
+                const uint32_t wc = W >> 1;
+                const size_t ic = (size_t)rp * wc + (x >> 1);
+                uint32_t cb_a = (Cb0[0] + Cb0[1] + Cb1[0] + Cb1[1]) >> 2, cb_b = (Cb0[2] + Cb0[3] + Cb1[2] + Cb1[3]) >> 2;
+                uint32_t cr_a = (Cr0[0] + Cr0[1] + Cr1[0] + Cr1[1]) >> 2, cr_b = (Cr0[2] + Cr0[3] + Cr1[2] + Cr1[3]) >> 2;
+                cb_a = pix_yuv_clamp(pp, cb_a, true); cb_b = pix_yuv_clamp(pp, cb_b, true);
+                cr_a = pix_yuv_clamp(pp, cr_a, true); cr_b = pix_yuv_clamp(pp, cr_b, true);
+                uint16_t *Cbp = io.out + npix, *Crp = Cbp + (size_t)wc * (H >> 1);
+                *reinterpret_cast<uint32_t *>(Cbp + ic) = cb_a | (cb_b << 16);
+                *reinterpret_cast<uint32_t *>(Crp + ic) = cr_a | (cr_b << 16);
+            } else {
+                uint16_t *Cbp, *Crp;
+                if (OUT_KIND == H2Y_OUT_444) {
+                    Cbp = io.out + npix;
+                    Crp = Cbp + npix;
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        Cb0[j] = pix_yuv_clamp(pp, Cb0[j], true); Cb1[j] = pix_yuv_clamp(pp, Cb1[j], true);
+                        Cr0[j] = pix_yuv_clamp(pp, Cr0[j], true); Cr1[j] = pix_yuv_clamp(pp, Cr1[j], true);
+                    }
+                } else {
+                    Cbp = io.tmp_cb;
+                    Crp = io.tmp_cr;
+                }
+                *reinterpret_cast<uint2 *>(Cbp + i0) = make_uint2(Cb0[0] | (Cb0[1] << 16), Cb0[2] | (Cb0[3] << 16));
+                *reinterpret_cast<uint2 *>(Crp + i0) = make_uint2(Cr0[0] | (Cr0[1] << 16), Cr0[2] | (Cr0[3] << 16));
+                if (row1) {
+                    *reinterpret_cast<uint2 *>(Cbp + i1) = make_uint2(Cb1[0] | (Cb1[1] << 16), Cb1[2] | (Cb1[3] << 16));
+                    *reinterpret_cast<uint2 *>(Crp + i1) = make_uint2(Cr1[0] | (Cr1[1] << 16), Cr1[2] | (Cr1[3] << 16));
+                }
+            }
+        }
+        block_store_mm<H2Y_FUSED_THREADS / WAVE>(mm, s_red, a.partial + ((size_t)f * G + blockIdx.x) * 6);
+    }
+}
+
+/*
+ * Generic-width variant (width % 4 != 0, so rows are not 16-byte aligned):
+ * one thread = 1 column x 2 rows, 4:4:4 or 4:4:4-to-scratch only (box needs
+ * width % 4 == 0).  Correctness path for odd sizes, not tuned.
+ */
+template <int IN_KIND, int OUT_KIND>
+__global__ __launch_bounds__(H2Y_FUSED_THREADS) void k_fused_narrow(fused_args a)
+{
+    __shared__ pq_recA sA[H2Y_PQ_NSEG];
+    __shared__ pq_recB sB[H2Y_PQ_NSEG];
+    __shared__ float s_red[(H2Y_FUSED_THREADS / WAVE) * 6];
+    if (a.pp.convert_transfer) {
+        const uint4 *gA = reinterpret_cast<const uint4 *>(a.table);
+        const uint4 *gB = gA + H2Y_PQ_NSEG;
+        uint4 *lA = reinterpret_cast<uint4 *>(sA), *lB = reinterpret_cast<uint4 *>(sB);
+        for (int i = threadIdx.x; i < H2Y_PQ_NSEG; i += H2Y_FUSED_THREADS) {
+            lA[i] = gA[i];
+            lB[i] = gB[i];
+        }
+    }
+    __syncthreads();
+    typedef in_traits<IN_KIND> IN;
+    const pix_params pp = with_assumed(a.pp, a.assumed);
+    const uint32_t W = a.width, H = a.height;
+    const size_t npix = (size_t)W * H;
+    const uint32_t G = gridDim.x;
+    for (int f = 0; f < a.n_frames; f++) {
+        const frame_io io = a.frames[f];
+        mm6 mm;
+        mm.reset();
+        const uint32_t gbase = (uint32_t)(((uint64_t)f * a.chunks_per_frame) % G);
+        uint32_t k = (blockIdx.x + G - gbase) % G;
+        for (; k < a.chunks_per_frame; k += G) {
+            const uint32_t tt = k * H2Y_FUSED_THREADS + threadIdx.x;
+            if (tt >= a.tiles_per_frame) continue;
+            uint32_t x;
+            const uint32_t rp = udiv_magic(tt, W, a.wq_magic, x);
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++) {
+                const uint32_t y = rp * 2 + rr;
+                if (y >= H) break;
+                const size_t i = (size_t)y * W + x;
+                float g = IN::load1(io.in[0], i), b = IN::load1(io.in[1], i), r = IN::load1(io.in[2], i);
+                mm.add(0, g); mm.add(1, b); mm.add(2, r);
+                uint32_t Y, Cb, Cr;
+                pixel(pp, sA, sB, g, b, r, Y, Cb, Cr);
+                io.out[i] = (uint16_t)pix_yuv_clamp(pp, Y, false);
+                if (OUT_KIND == H2Y_OUT_444) {
+                    io.out[npix + i] = (uint16_t)pix_yuv_clamp(pp, Cb, true);
+                    io.out[2 * npix + i] = (uint16_t)pix_yuv_clamp(pp, Cr, true);
+                } else {
+                    io.tmp_cb[i] = (uint16_t)Cb;
+                    io.tmp_cr[i] = (uint16_t)Cr;
+                }
+            }
+        }
+        block_store_mm<H2Y_FUSED_THREADS / WAVE>(mm, s_red, a.partial + ((size_t)f * G + blockIdx.x) * 6);
+    }
+}
+
+/* ---- pic_stats() as a pre-pass, common.cpp:116-139 ---------------------- */
+template <int IN_KIND>
+__global__ __launch_bounds__(H2Y_FUSED_THREADS) void k_stats(stats_args a)
+{
+    __shared__ float s_red[(H2Y_FUSED_THREADS / WAVE) * 6];
+    typedef in_traits<IN_KIND> IN;
+    mm6 mm;
+    mm.reset();
+    const size_t n = a.npix, n4 = a.vec_ok ? n / 4 : 0;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            float v[4];
+            IN::load4(a.in[c], i * 4, v);
+#pragma unroll
+            for (int j = 0; j < 4; j++) mm.add(c, v[j]);
+        }
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+#pragma unroll
+        for (int c = 0; c < 3; c++) mm.add(c, IN::load1(a.in[c], i));
+    block_store_mm<H2Y_FUSED_THREADS / WAVE>(mm, s_red, a.partial + (size_t)blockIdx.x * 6);
+}
+
+/*
+ * k_stats_final: one block per frame.  Reduces partial[frame][0..nblk) to the
+ * six floats, derives estimated_floor/ceiling and compares with the values
+ * the fused kernel assumed.
+ *   F32/F16: (int)min, (int)max                     common.cpp:135-136
+ *   U16    : min, max with the ceiling snap         common.cpp:91-106
+ */
+__global__ __launch_bounds__(256) void k_stats_final(final_args a)
+{
+    __shared__ float s_red[4 * 6];
+    const int f = blockIdx.x;
+    const float *p = a.partial + (size_t)f * a.nblk * 6;
+    mm6 mm;
+    mm.reset();
+    for (int i = threadIdx.x; i < a.nblk; i += blockDim.x)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            /* plain min/max: partials are never NaN (fminf/fmaxf dropped them) */
+            mm.lo[c] = fminf(mm.lo[c], p[i * 6 + 2 * c]);
+            mm.hi[c] = fmaxf(mm.hi[c], p[i * 6 + 2 * c + 1]);
+        }
+    frame_stats *out = a.out + f;
+    block_store_mm<4>(mm, s_red, out->mm);
+    if (threadIdx.x == 0) {
+        int bad = 0;
+        for (int c = 0; c < 3; c++) {
+            float lo = out->mm[2 * c], hi = out->mm[2 * c + 1];
+            int fl, ce;
+            if (a.is_u16) {
+                fl = (int)lo;
+                ce = (int)hi;
+                const int D = 1 << (a.src_bit_depth - 8), SMin = D * 16;
+                const int YMax = 219 * D + SMin, CMax = 224 * D + SMin;
+                if (ce < YMax && ce > (YMax * 3) / 4) ce = YMax;
+                if (ce < CMax && ce > (CMax * 3) / 4) ce = CMax;
+            } else {
+                /* C truncation; the reference leaves |v| >= 2^31 undefined,
+                 * we saturate (unpinned) */
+                lo = fminf(fmaxf(lo, -2147483648.0f), 2147483520.0f);
+                hi = fminf(fmaxf(hi, -2147483648.0f), 2147483520.0f);
+                fl = (int)lo;
+                ce = (int)hi;
+            }
+            out->floor_[c] = fl;
+            out->ceil_[c] = ce;
+            if (a.check && (fl != a.assumed->floor_[c] || ce != a.assumed->ceil_[c])) bad = 1;
+            if (a.publish && f == 0) {
+                a.publish->floor_[c] = fl;
+                a.publish->ceil_[c] = ce;
+            }
+        }
+        out->mismatch = bad;
+    }
+}
+
+/* ---- Subsample444to420_box as a stand-alone stage, convert.cpp:91-172 --- */
+__global__ __launch_bounds__(256) void k_box420(const uint16_t *__restrict__ src, uint16_t *__restrict__ dst, int W, int H)
+{
+    const int wc = W >> 1, hc = H >> 1;
+    const int xc = blockIdx.x * blockDim.x + threadIdx.x, yc = blockIdx.y;
+    if (xc >= wc || yc >= hc) return;
+    const uint32_t *r0 = reinterpret_cast<const uint32_t *>(src + (size_t)(2 * yc) * W);
+    const uint32_t *r1 = reinterpret_cast<const uint32_t *>(src + (size_t)(2 * yc + 1) * W);
+    uint32_t a = r0[xc], b = r1[xc];
+    dst[(size_t)yc * wc + xc] = (uint16_t)(((a & 0xFFFF) + (a >> 16) + (b & 0xFFFF) + (b >> 16)) >> 2);
+}
+
+/*
+ * k_fir420: Subsample444to420_FIR (convert.cpp:261-383) for one plane, then
+ * the write_yuv clamp.  Block = output tile FIR_TW x FIR_TH chroma samples.
+ *   1. stage the 4:4:4 source rows 2*r0-5 .. 2*r0+2*FIR_TH+4, columns
+ *      2*c0-5 .. 2*c0+2*FIR_TW+4 into LDS with the reference's edge
+ *      replication (indices clamped, convert.cpp:295-300, :337-347)
+ *   2. horizontal 7-tap -> u16 4:2:2 tile in LDS (clamped + truncated exactly
+ *      as the reference stores dst422, convert.cpp:314-317)
+ *   3. vertical 12-tap -> 4:2:0 sample, clamp, truncate, then shift + range
+ *      clamp of write_yuv
+ */
+#define FIR_TW 64
+#define FIR_TH 16
+#define FIR_ROWS (2 * FIR_TH + 10)
+#define FIR_COLS (2 * FIR_TW + 10)
+
+__global__ __launch_bounds__(256) void k_fir420(fir_args a)
+{
+    __shared__ uint16_t s444[FIR_ROWS][FIR_COLS + 2];
+    __shared__ uint16_t s422[FIR_ROWS][FIR_TW];
+    const int W = a.width, H = a.height, wc = W >> 1, hc = H >> 1;
+    const uint16_t *src = blockIdx.z == 0 ? a.src_cb : a.src_cr;
+    uint16_t *dst = blockIdx.z == 0 ? a.dst_cb : a.dst_cr;
+    const int c0 = blockIdx.x * FIR_TW, r0 = blockIdx.y * FIR_TH;
+    const int ys = 2 * r0 - 5, xs = 2 * c0 - 5;
+
+    for (int i = threadIdx.x; i < FIR_ROWS * FIR_COLS; i += 256) {
+        int r = i / FIR_COLS, c = i - r * FIR_COLS;
+        int y = min(max(ys + r, 0), H - 1), x = min(max(xs + c, 0), W - 1);
+        s444[r][c] = src[(size_t)y * W + x];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < FIR_ROWS * FIR_TW; i += 256) {
+        int r = i / FIR_TW, c = i - r * FIR_TW;
+        const uint16_t *s = &s444[r][2 * c]; /* s[5] is the even column 2*(c0+c) */
+        /* In-picture rows only matter; out-of-picture rows were replicated
+         * from the edge row, giving the same 4:2:2 value the reference reads
+         * through its clamped row index. */
+        s422[r][c] = (uint16_t)fir_h((float)s[0], (float)s[2], (float)s[4], (float)s[5], (float)s[6], (float)s[8],
+                                     (float)s[10], a.fir_max);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < FIR_TH * FIR_TW; i += 256) {
+        int r = i / FIR_TW, c = i - r * FIR_TW;
+        int yo = r0 + r, xo = c0 + c;
+        if (yo >= hc || xo >= wc) continue;
+        const int b = 2 * r; /* s422 row of source row 2*yo-5 */
+        uint32_t v = fir_v((float)s422[b][c], (float)s422[b + 1][c], (float)s422[b + 2][c], (float)s422[b + 3][c],
+                           (float)s422[b + 4][c], (float)s422[b + 5][c], (float)s422[b + 6][c], (float)s422[b + 7][c],
+                           (float)s422[b + 8][c], (float)s422[b + 9][c], (float)s422[b + 10][c], (float)s422[b + 11][c],
+                           a.fir_max);
+        if (a.apply_yuv_clamp) v = pix_yuv_clamp(a.pp, v, true);
+        dst[(size_t)yo * wc + xo] = (uint16_t)v;
+    }
+}
+
+/* ---- launch helpers (called from h2y_api.hip) --------------------------- */
+template <int IN_KIND>
+static hipError_t launch_fused_in(int out_kind, bool narrow, dim3 grid, hipStream_t st, const fused_args &a)
+{
+    dim3 blk(H2Y_FUSED_THREADS);
+    if (narrow) {
+        if (out_kind == H2Y_OUT_444) hipLaunchKernelGGL((k_fused_narrow<IN_KIND, H2Y_OUT_444>), grid, blk, 0, st, a);
+        else hipLaunchKernelGGL((k_fused_narrow<IN_KIND, H2Y_OUT_444TMP>), grid, blk, 0, st, a);
+    } else if (out_kind == H2Y_OUT_420BOX) hipLaunchKernelGGL((k_fused<IN_KIND, H2Y_OUT_420BOX>), grid, blk, 0, st, a);
+    else if (out_kind == H2Y_OUT_444) hipLaunchKernelGGL((k_fused<IN_KIND, H2Y_OUT_444>), grid, blk, 0, st, a);
+    else hipLaunchKernelGGL((k_fused<IN_KIND, H2Y_OUT_444TMP>), grid, blk, 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t h2y_launch_fused(int in_kind, int out_kind, bool narrow, int grid, hipStream_t st, const fused_args &a)
+{
+    switch (in_kind) {
+    case H2Y_IN_F32: return launch_fused_in<H2Y_IN_F32>(out_kind, narrow, dim3(grid), st, a);
+    case H2Y_IN_F16: return launch_fused_in<H2Y_IN_F16>(out_kind, narrow, dim3(grid), st, a);
+    default: return launch_fused_in<H2Y_IN_U16>(out_kind, narrow, dim3(grid), st, a);
+    }
+}
+
+hipError_t h2y_launch_stats(int in_kind, int grid, hipStream_t st, const stats_args &a)
+{
+    dim3 blk(H2Y_FUSED_THREADS);
+    switch (in_kind) {
+    case H2Y_IN_F32: hipLaunchKernelGGL((k_stats<H2Y_IN_F32>), dim3(grid), blk, 0, st, a); break;
+    case H2Y_IN_F16: hipLaunchKernelGGL((k_stats<H2Y_IN_F16>), dim3(grid), blk, 0, st, a); break;
+    default: hipLaunchKernelGGL((k_stats<H2Y_IN_U16>), dim3(grid), blk, 0, st, a); break;
+    }
+    return hipGetLastError();
+}
+
+hipError_t h2y_launch_stats_final(int n_frames, hipStream_t st, const final_args &a)
+{
+    hipLaunchKernelGGL(k_stats_final, dim3(n_frames), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t h2y_launch_fir420(hipStream_t st, const fir_args &a)
+{
+    const int wc = a.width >> 1, hc = a.height >> 1;
+    dim3 grid((wc + FIR_TW - 1) / FIR_TW, (hc + FIR_TH - 1) / FIR_TH, a.src_cr ? 2 : 1);
+    hipLaunchKernelGGL(k_fir420, grid, dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t h2y_launch_box420(hipStream_t st, const uint16_t *src, uint16_t *dst, int W, int H)
+{
+    const int wc = W >> 1, hc = H >> 1;
+    dim3 grid((wc + 255) / 256, hc);
+    hipLaunchKernelGGL(k_box420, grid, dim3(256), 0, st, src, dst, W, H);
+    return hipGetLastError();
+}

@@ -1,0 +1,261 @@
+"""GPU parity: the HIP path, called through the C-ABI, against the oracle
+(oracle/h2y_oracle.c, itself pinned to the reference's object code and to the
+SURVEY 8c md5s).  Integer output => the bar is bit-exact."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import hdr2yuv_amd as h
+from oracle import binding as ob
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _to_oracle_desc(d):
+    od = ob.H2YDesc()
+    for name, _ in h.H2YDesc._fields_:
+        v = getattr(d, name)
+        if name in ("floor", "ceiling"):
+            for c in range(3):
+                getattr(od, name)[c] = v[c]
+        else:
+            setattr(od, name, v)
+    return od
+
+
+def _rand_planes(rng, w, h_, kind, lo=0.0, hi=1.0, plant=True):
+    n = w * h_
+    planes = []
+    for _ in range(3):
+        p = rng.uniform(lo, hi, n).astype(np.float32)
+        # sprinkle exact zeros, tiny values and values that hit the slow tier's domain edges
+        idx = rng.integers(0, n, 8)
+        p[idx[:3]] = 0.0
+        p[idx[3:5]] = np.float32(2.0 ** -30)
+        p[idx[5:]] = np.float32(2.0 ** -24)
+        if plant:
+            p[0], p[1] = lo, hi
+        planes.append(p)
+    if kind == h.SAMPLE_F16:
+        return [p.astype(np.float16).view(np.uint16) for p in planes]
+    return planes
+
+
+CASES = []
+for mat in (h.MATRIX_BT2020NC, h.MATRIX_BT709, h.MATRIX_YDZDX, h.MATRIX_Y100, h.MATRIX_Y500, h.MATRIX_GBR):
+    for depth in (10, 12, 16):
+        for (chroma, res) in ((h.CHROMA_420, 0), (h.CHROMA_420, 1), (h.CHROMA_444, 0)):
+            CASES.append((mat, depth, chroma, res))
+
+
+@pytest.mark.parametrize("mat,depth,chroma,res", CASES)
+def test_frame_matches_oracle_f32(ctx, oracle, mat, depth, chroma, res):
+    rng = np.random.default_rng(1000 + mat * 31 + depth * 7 + chroma + res)
+    w, hh = 136, 52
+    for full in (0, 1):
+        d = h.make_desc(w, hh, dst_depth=depth, dst_matrix=mat, chroma=chroma, resampler=res, full_range=full)
+        planes = _rand_planes(rng, w, hh, h.SAMPLE_F32)
+        got = ctx.convert_frame(d, planes)
+        want = oracle.convert_frame(_to_oracle_desc(d), planes)
+        assert np.array_equal(got, want), f"{np.count_nonzero(got != want)} samples differ"
+
+
+@pytest.mark.parametrize("w,hh", [(4, 4), (8, 4), (64, 32), (132, 12), (260, 36), (1028, 8), (2052, 4)])
+@pytest.mark.parametrize("res", [0, 1])
+def test_ragged_sizes_420(ctx, oracle, w, hh, res):
+    rng = np.random.default_rng(w * 131 + hh)
+    d = h.make_desc(w, hh, dst_depth=12, dst_matrix=h.MATRIX_BT2020NC, resampler=res)
+    planes = _rand_planes(rng, w, hh, h.SAMPLE_F32)
+    got = ctx.convert_frame(d, planes)
+    want = oracle.convert_frame(_to_oracle_desc(d), planes)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("w,hh", [(1, 1), (3, 5), (7, 2), (130, 3), (33, 33), (66, 10)])
+def test_odd_sizes_444_and_fir(ctx, oracle, w, hh):
+    rng = np.random.default_rng(w * 17 + hh)
+    planes = _rand_planes(rng, w, hh, h.SAMPLE_F32, plant=(w * hh >= 2))
+    stats = None if w * hh >= 2 else [(0, 1)] * 3
+    d = h.make_desc(w, hh, dst_depth=16, dst_matrix=h.MATRIX_YDZDX, chroma=h.CHROMA_444, stats=stats)
+    assert np.array_equal(ctx.convert_frame(d, planes), oracle.convert_frame(_to_oracle_desc(d), planes))
+    if w % 2 == 0 and hh % 2 == 0:
+        d = h.make_desc(w, hh, dst_depth=10, dst_matrix=h.MATRIX_BT709, resampler=1)
+        assert np.array_equal(ctx.convert_frame(d, planes), oracle.convert_frame(_to_oracle_desc(d), planes))
+
+
+def test_f16_input(ctx, oracle):
+    rng = np.random.default_rng(5)
+    w, hh = 256, 64
+    for res in (0, 1):
+        d = h.make_desc(w, hh, sample=h.SAMPLE_F16, dst_depth=10, dst_matrix=h.MATRIX_BT2020NC, resampler=res)
+        planes = _rand_planes(rng, w, hh, h.SAMPLE_F16)
+        assert np.array_equal(ctx.convert_frame(d, planes), oracle.convert_frame(_to_oracle_desc(d), planes))
+
+
+def test_normalisation_with_nontrivial_stats(ctx, oracle):
+    """floor/ceiling other than 0/1: (x - offset) / range in binary32 with an IEEE divide."""
+    rng = np.random.default_rng(11)
+    w, hh = 128, 32
+    planes = [rng.uniform(2.3, 9.7, w * hh).astype(np.float32), rng.uniform(-3.9, 5.2, w * hh).astype(np.float32),
+              rng.uniform(0.0, 3.999, w * hh).astype(np.float32)]
+    # keep normalised values non-negative: floor is (int)min which truncates toward zero
+    planes[1] = np.abs(planes[1]) + np.float32(1.0)
+    d = h.make_desc(w, hh, dst_depth=12, dst_matrix=h.MATRIX_BT2020NC, resampler=1)
+    got = ctx.convert_frame(d, planes)
+    want = oracle.convert_frame(_to_oracle_desc(d), planes)
+    assert np.array_equal(got, want)
+    # and the same through an explicit override
+    d2 = h.make_desc(w, hh, dst_depth=12, dst_matrix=h.MATRIX_BT2020NC, resampler=0, stats=[(2, 9), (1, 6), (0, 3)])
+    assert np.array_equal(ctx.convert_frame(d2, planes), oracle.convert_frame(_to_oracle_desc(d2), planes))
+
+
+def test_same_transfer_passthrough(ctx, oracle):
+    """src transfer == dst transfer: no normalisation, no PQ, no scaling (convert.cpp:930,1012)."""
+    rng = np.random.default_rng(12)
+    w, hh = 64, 16
+    planes = [rng.uniform(0, 1000, w * hh).astype(np.float32) for _ in range(3)]
+    d = h.make_desc(w, hh, dst_depth=10, src_transfer=h.TRANSFER_PQ, dst_transfer=h.TRANSFER_PQ,
+                    dst_matrix=h.MATRIX_BT709, resampler=1)
+    assert np.array_equal(ctx.convert_frame(d, planes), oracle.convert_frame(_to_oracle_desc(d), planes))
+
+
+def test_u16_input(ctx, oracle):
+    """16-bit integer input, shifted down in write_yuv."""
+    rng = np.random.default_rng(13)
+    w, hh = 128, 32
+    planes = [rng.integers(0, 65536, w * hh).astype(np.uint16) for _ in range(3)]
+    for dst_depth, mat in ((10, h.MATRIX_YDZDX), (12, h.MATRIX_BT2020NC), (16, h.MATRIX_BT709)):
+        for res in (0, 1):
+            d = h.make_desc(w, hh, sample=h.SAMPLE_U16, src_depth=16, dst_depth=dst_depth, src_transfer=h.TRANSFER_PQ,
+                            dst_transfer=h.TRANSFER_PQ, dst_matrix=mat, resampler=res)
+            assert np.array_equal(ctx.convert_frame(d, planes), oracle.convert_frame(_to_oracle_desc(d), planes))
+    # with a transfer change the U16 stats heuristics (common.cpp:94-106) feed the normalisation
+    d = h.make_desc(w, hh, sample=h.SAMPLE_U16, src_depth=16, dst_depth=12, dst_matrix=h.MATRIX_BT2020NC, resampler=1)
+    assert np.array_equal(ctx.convert_frame(d, planes), oracle.convert_frame(_to_oracle_desc(d), planes))
+
+
+def test_golden_fixtures(ctx):
+    with open(os.path.join(GOLD, "index.json")) as f:
+        index = json.load(f)
+    assert index["cases"]
+    for case in index["cases"]:
+        z = np.load(os.path.join(GOLD, case["file"]))
+        d = h.make_desc(**case["desc"])
+        planes = [z["in0"], z["in1"], z["in2"]]
+        got = ctx.convert_frame(d, planes)
+        assert np.array_equal(got, z["yuv"]), case["file"]
+
+
+def _md5(a):
+    return hashlib.md5(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+KNOWN = json.load(open(os.path.join(GOLD, "known_md5.json")))
+
+
+@pytest.mark.parametrize("name", sorted(KNOWN["cases"].keys()))
+def test_full_size_known_md5(ctx, oracle, name):
+    """BASELINE configs at full size against the md5 of the reference's own .yuv
+    (SURVEY 8c), without running the oracle."""
+    case = KNOWN["cases"][name]
+    d = h.make_desc(**case["desc"])
+    planes = oracle.synth_frame(d.width, d.height, 0, f16=(d.in_sample_type == h.SAMPLE_F16))
+    got = ctx.convert_frame(d, planes)
+    assert got.nbytes == case["bytes"]
+    assert _md5(got) == case["md5"]
+
+
+def test_batch_device_path_and_stats_redo(ctx, oracle):
+    """h2y_convert_batch on device buffers: frames 0..3 share floor/ceiling, frame 4
+    does not (its maximum is 2.5) so the assumption fails and it is re-run."""
+    import torch
+
+    rng = np.random.default_rng(21)
+    w, hh = 256, 64
+    d = h.make_desc(w, hh, dst_depth=12, dst_matrix=h.MATRIX_BT2020NC, resampler=0)
+    host = [_rand_planes(rng, w, hh, h.SAMPLE_F32) for _ in range(6)]
+    host[4][1][7] = np.float32(2.5)
+    host[5][0][9] = np.float32(1.5)  # (int)1.5 == 1: same stats as the others
+    dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in host]
+    nb = h.frame_bytes(d)
+    dev_out = [torch.empty(nb // 2, dtype=torch.int16, device="cuda") for _ in host]
+    torch.cuda.synchronize()
+    fresh = h.Context(0)
+    try:
+        fresh.convert_batch_enqueue(d, dev_in, dev_out)
+        redone = fresh.batch_finish()
+        assert redone == 1
+        od = _to_oracle_desc(d)
+        for f in range(len(host)):
+            got = dev_out[f].cpu().numpy().view(np.uint16)
+            assert np.array_equal(got, oracle.convert_frame(od, host[f])), f"frame {f}"
+        # second batch: the hint is now frame 5's stats; everything but frame 4 passes
+        for t in dev_out:
+            t.zero_()
+        fresh.convert_batch(d, dev_in, dev_out)
+        for f in range(len(host)):
+            got = dev_out[f].cpu().numpy().view(np.uint16)
+            assert np.array_equal(got, oracle.convert_frame(od, host[f])), f"frame {f} (2nd batch)"
+        ms, n = fresh.last_kernel_ms()
+        assert n >= 1 and ms > 0
+    finally:
+        fresh.close()
+
+
+def test_batch_fir(ctx, oracle):
+    import torch
+
+    rng = np.random.default_rng(22)
+    w, hh = 192, 48
+    d = h.make_desc(w, hh, dst_depth=10, dst_matrix=h.MATRIX_BT709, resampler=1)
+    host = [_rand_planes(rng, w, hh, h.SAMPLE_F32) for _ in range(11)]  # > FIR sub-batch of 8
+    dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in host]
+    dev_out = [torch.empty(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda") for _ in host]
+    torch.cuda.synchronize()
+    ctx.convert_batch(d, dev_in, dev_out)
+    od = _to_oracle_desc(d)
+    for f in range(len(host)):
+        assert np.array_equal(dev_out[f].cpu().numpy().view(np.uint16), oracle.convert_frame(od, host[f])), f
+
+
+def test_stage_entries(ctx, oracle):
+    """pic_stats / matrix_convert / subsample as separate calls, like the reference's main()."""
+    import torch
+
+    rng = np.random.default_rng(23)
+    w, hh = 128, 32
+    planes = _rand_planes(rng, w, hh, h.SAMPLE_F32, lo=0.0, hi=3.7)
+    dev = [torch.from_numpy(p).cuda() for p in planes]
+    d = h.make_desc(w, hh, dst_depth=12, dst_matrix=h.MATRIX_BT2020NC, resampler=1)
+    mm, fc = ctx.pic_stats(d, dev)
+    omm, ofl, oce = oracle.stats_f32(planes)
+    assert np.array_equal(np.float32(mm), omm)
+    assert fc[0::2] == list(ofl) and fc[1::2] == list(oce)
+    for c in range(3):
+        d.floor[c], d.ceiling[c] = fc[2 * c], fc[2 * c + 1]
+    out = [torch.empty(w * hh, dtype=torch.int16, device="cuda") for _ in range(3)]
+    ctx.matrix_convert(d, dev, out)
+    want = oracle.matrix_convert(_to_oracle_desc(d), planes, ofl, oce, 12)
+    for c in range(3):
+        assert np.array_equal(out[c].cpu().numpy().view(np.uint16), want[c])
+    for res in (0, 1):
+        dst = torch.empty((hh // 2) * (w // 2), dtype=torch.int16, device="cuda")
+        ctx.subsample_420(w, hh, 12, res, out[1], dst)
+        ref = oracle.sub420(want[1].reshape(hh, w), 12, fir=bool(res))
+        assert np.array_equal(dst.cpu().numpy().view(np.uint16).reshape(hh // 2, w // 2), ref)
+
+
+def test_descriptor_errors(ctx):
+    d = h.make_desc(64, 32, dst_matrix=4)  # MATRIX_FCC: the reference exit(0)s (convert.cpp:1196)
+    with pytest.raises(h.H2YError) as e:
+        ctx.convert_frame(d, [np.zeros(64 * 32, np.float32)] * 3)
+    assert e.value.code == 2
+    d = h.make_desc(66, 32, resampler=0)  # box needs multiples of 4
+    with pytest.raises(h.H2YError) as e:
+        ctx.convert_frame(d, [np.zeros(66 * 32, np.float32)] * 3)
+    assert e.value.code == 1

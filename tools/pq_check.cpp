@@ -1,0 +1,124 @@
+/*
+ * tools/pq_check.cpp -- TEST TOOL (host build of hdr2yuv_amd/csrc/h2y_math.h).
+ *
+ * Checks the two PQ tiers of the device arithmetic against the reference
+ * formula evaluated with this machine's libm (what convert.cpp:56-63 does):
+ *
+ *   pq_check pow   N            random pow_dd() vs libm pow(), both exponents
+ *   pq_check range LO HI [T]    every float with bit pattern in [LO,HI):
+ *                               fast tier (+ slow when flagged) vs libm PQ;
+ *                               reports mismatches, slow-tier rate and the
+ *                               largest fast-tier error in double ulps
+ *   pq_check slow  LO HI [T]    same range, slow tier only
+ *
+ * Build: g++ -O2 -ffp-contract=off -mfma -std=c++17 -pthread
+ */
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <thread>
+#include <vector>
+
+#include "../hdr2yuv_amd/csrc/h2y_math.h"
+
+using namespace h2y;
+
+static inline double ref_chain(float L, float *vf)
+{
+    double Ln = pow((double)L, 0.1593017578);
+    double V = pow((0.8359375 + 18.8515625 * Ln) / (1 + 18.6875 * Ln), 78.84375);
+    *vf = (float)V;
+    return V;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) return 2;
+    if (!strcmp(argv[1], "pow")) {
+        long n = argc > 2 ? atol(argv[2]) : 10000000;
+        std::mt19937_64 rng(1);
+        long bad1 = 0, bad2 = 0, big = 0;
+        for (long i = 0; i < n; i++) {
+            uint32_t b = (uint32_t)(rng() % 0x7F800000u);
+            if (b == 0) b = 1;
+            float xf = bits2f(b);
+            double a = pow((double)xf, H2Y_PQ_M1), m = pow_dd((double)xf, H2Y_PQ_M1);
+            if (a != m) {
+                bad1++;
+                if (fabs((double)(int64_t)(d2bits(a) - d2bits(m))) > 1) big++;
+            }
+            double base = 0.83 + (rng() >> 11) * 0x1p-53 * 0.18;
+            a = pow(base, H2Y_PQ_M2);
+            m = pow_dd(base, H2Y_PQ_M2);
+            if (a != m) {
+                bad2++;
+                if (fabs((double)(int64_t)(d2bits(a) - d2bits(m))) > 1) big++;
+            }
+        }
+        printf("pow_dd vs libm: m1 differ %ld / %ld (%.4f%%), m2 differ %ld (%.4f%%), >1ulp: %ld\n", bad1, n,
+               100.0 * bad1 / n, bad2, 100.0 * bad2 / n, big);
+        return 0;
+    }
+    bool slow_only = !strcmp(argv[1], "slow");
+    uint32_t lo = (uint32_t)strtoul(argv[2], 0, 0), hi = (uint32_t)strtoul(argv[3], 0, 0);
+    int T = argc > 4 ? atoi(argv[4]) : 8;
+    std::vector<pq_recA> A(H2Y_PQ_NSEG);
+    std::vector<pq_recB> B(H2Y_PQ_NSEG);
+    pq_build_table(A.data(), B.data());
+    std::atomic<uint64_t> mism{0}, nslow{0}, maxerr{0}, total{0};
+    std::vector<std::thread> th;
+    uint64_t span = (uint64_t)hi - lo;
+    for (int t = 0; t < T; t++) {
+        th.emplace_back([&, t]() {
+            uint64_t a = lo + span * t / T, b = lo + span * (t + 1) / T;
+            uint64_t mm = 0, ns = 0, me = 0;
+            for (uint64_t u = a; u < b; u++) {
+                float x = bits2f((uint32_t)u);
+                float want;
+                double vref = ref_chain(x, &want);
+                float got;
+                if (slow_only) {
+                    got = pq_slow(x);
+                    ns++;
+                } else {
+                    bool slow;
+                    got = pq_fast(x, A.data(), B.data(), &slow);
+                    if (slow) {
+                        got = pq_slow(x);
+                        ns++;
+                    } else {
+                        /* fast-tier error in double ulps: recompute v */
+                        uint32_t bits = (uint32_t)u;
+                        uint32_t idx = (bits - (H2Y_PQ_SEG_BASE << H2Y_PQ_LOW_BITS)) >> H2Y_PQ_LOW_BITS;
+                        float f = bits2f((bits & ((1u << H2Y_PQ_LOW_BITS) - 1u)) | 0x3F800000u);
+                        float uu = __builtin_fmaf(f, 128.0f, -129.0f);
+                        float p = __builtin_fmaf(B[idx].c4, uu, B[idx].c3);
+                        double ud = uu, v = __builtin_fma((double)p, ud, B[idx].c2);
+                        v = __builtin_fma(v, ud, A[idx].c1);
+                        v = __builtin_fma(v, ud, A[idx].c0);
+                        int64_t d = (int64_t)(d2bits(v) - d2bits(vref));
+                        uint64_t ad = d < 0 ? -d : d;
+                        if (ad > me) me = ad;
+                    }
+                }
+                if (f2bits(got) != f2bits(want) && !(got != got && want != want)) {
+                    mm++;
+                    if (mm < 5) fprintf(stderr, "MISMATCH x=%a (0x%08x) got %a want %a\n", x, (uint32_t)u, got, want);
+                }
+            }
+            mism += mm;
+            nslow += ns;
+            total += b - a;
+            uint64_t cur = maxerr.load();
+            while (me > cur && !maxerr.compare_exchange_weak(cur, me)) {}
+        });
+    }
+    for (auto &x : th) x.join();
+    printf("range [0x%08x,0x%08x): %llu floats, mismatches %llu, slow tier %llu (1 in %.0f), max fast err %llu ulp(double)\n",
+           lo, hi, (unsigned long long)total.load(), (unsigned long long)mism.load(),
+           (unsigned long long)nslow.load(), nslow ? (double)total / nslow : 0.0, (unsigned long long)maxerr.load());
+    return mism ? 1 : 0;
+}

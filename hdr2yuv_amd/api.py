@@ -73,7 +73,8 @@ def make_desc(width, height, *, sample=SAMPLE_F32, src_depth=32, dst_depth=10, s
 
 
 def library_path() -> str:
-    return os.path.join(_HERE, "libhdr2yuv_hip.so")
+    # H2Y_LIB: tuning experiments load an alternative build of the same library
+    return os.environ.get("H2Y_LIB") or os.path.join(_HERE, "libhdr2yuv_hip.so")
 
 
 def build_library(force: bool = False) -> str:

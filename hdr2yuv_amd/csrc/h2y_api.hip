@@ -147,16 +147,13 @@ void derive_params(const h2y_desc *d, pix_params *pp, bool stage_matrix_only)
     const clip_limits tc = make_clip(tmp_depth, d->dst_full_range);
     const clip_limits oc = make_clip(d->dst_bit_depth, d->dst_full_range);
     pp->convert_transfer = d->src_transfer != d->dst_transfer; /* convert.cpp:930 */
-    /* convert.cpp:1123-1145 */
+    /* convert.cpp:1123-1145 (full range: multiply only; add stays 0.0f) */
     if (d->dst_full_range) {
-        pp->scale_mode = H2Y_SCALE_FULL;
         pp->mulY = pp->mulC = (float)tc.maxCV;
     } else if (d->dst_matrix == H2Y_MATRIX_GBR) {
-        pp->scale_mode = H2Y_SCALE_GBR;
         pp->mulY = pp->mulC = (float)(int)tc.maxVR;
         pp->addY = pp->addC = (float)(int)tc.minVR;
     } else {
-        pp->scale_mode = H2Y_SCALE_YCC;
         pp->mulY = (float)(int)tc.maxVR;
         pp->addY = (float)(int)tc.minVR;
         pp->mulC = (float)(int)tc.maxVRC;
@@ -185,13 +182,16 @@ void derive_params(const h2y_desc *d, pix_params *pp, bool stage_matrix_only)
     pp->fir_max = (float)tc.maxCV;
     if (stage_matrix_only) { /* identity clamp: values are already <= maxCV <= 65535 */
         pp->down_shift = 0;
-        pp->full_range = 1;
-        pp->out_maxCV = 0xFFFFu;
+        pp->ylo = pp->clo = 0;
+        pp->yhi = pp->chi = 0xFFFFu;
     } else {
         pp->down_shift = tmp_depth - d->dst_bit_depth; /* tiff.cpp:394 */
-        pp->full_range = d->dst_full_range;
-        pp->ylo = oc.minVR; pp->yhi = oc.maxVR; pp->clo = oc.minVRC; pp->chi = oc.maxVRC;
-        pp->out_maxCV = oc.maxCV;
+        if (d->dst_full_range) { /* tiff.cpp:476: only "> maxCV" */
+            pp->ylo = pp->clo = 0;
+            pp->yhi = pp->chi = oc.maxCV;
+        } else {
+            pp->ylo = oc.minVR; pp->yhi = oc.maxVR; pp->clo = oc.minVRC; pp->chi = oc.maxVRC;
+        }
     }
 }
 
@@ -211,9 +211,10 @@ geom make_geom(const h2y_desc *d)
     return g;
 }
 
-int grid_for(const h2y_ctx *ctx, uint64_t total_chunks)
+int grid_for(const h2y_ctx *ctx, const h2y_desc *d, int out_kind, int mode, bool narrow, uint64_t total_chunks)
 {
-    uint64_t g = (uint64_t)ctx->n_cu * 2; /* 2 x 512 threads per CU: LDS 51 KB + <=128 VGPR each */
+    /* persistent grid: exactly the blocks the chip holds at once */
+    uint64_t g = (uint64_t)ctx->n_cu * h2y_fused_blocks_per_cu(in_kind_of(d), out_kind, mode, narrow);
     if (g > total_chunks) g = total_chunks;
     if (g < 1) g = 1;
     return (int)g;
@@ -252,7 +253,7 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         }
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frames + f0, ctx->h_frames + f0, nf * sizeof(frame_io), hipMemcpyHostToDevice,
                                     ctx->stream));
-        const int grid = grid_for(ctx, (uint64_t)g.chunks * nf);
+        const int grid = grid_for(ctx, d, out_kind, pp.mode, g.narrow, (uint64_t)g.chunks * nf);
         int rc = ensure(ctx, ctx->d_partial, ctx->partial_cap, (size_t)nf * grid * 6 * sizeof(float));
         if (rc) return rc;
         fused_args a;
@@ -270,7 +271,7 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         a.pp = pp;
         const bool ev = time_it && ctx->n_ev < kMaxEvents;
         if (ev) HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->n_ev][0], ctx->stream));
-        HIP_TRY(ctx, h2y_launch_fused(in_kind_of(d), out_kind, g.narrow, grid, ctx->stream, a));
+        HIP_TRY(ctx, h2y_launch_fused(in_kind_of(d), out_kind, pp.mode, g.narrow, grid, ctx->stream, a));
         if (ev) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->n_ev][1], ctx->stream));
             ctx->n_ev++;
@@ -443,12 +444,12 @@ int h2y_ctx_create(int device, h2y_ctx **out)
     }
     /* PQ fast-tier table: built on the host once, lives in HBM, staged to LDS per block */
     {
-        std::vector<pq_recA> A(H2Y_PQ_NSEG);
-        std::vector<pq_recB> B(H2Y_PQ_NSEG);
+        std::vector<pq_recA> A(H2Y_PQ_NREC);
+        std::vector<pq_recB> B(H2Y_PQ_NREC);
         pq_build_table(A.data(), B.data());
         HIP_TRY(ctx, hipMalloc(&ctx->d_table, H2Y_PQ_TABLE_BYTES));
-        HIP_TRY(ctx, hipMemcpy(ctx->d_table, A.data(), H2Y_PQ_NSEG * sizeof(pq_recA), hipMemcpyHostToDevice));
-        HIP_TRY(ctx, hipMemcpy((char *)ctx->d_table + H2Y_PQ_NSEG * sizeof(pq_recA), B.data(), H2Y_PQ_NSEG * sizeof(pq_recB),
+        HIP_TRY(ctx, hipMemcpy(ctx->d_table, A.data(), H2Y_PQ_NREC * sizeof(pq_recA), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy((char *)ctx->d_table + H2Y_PQ_NREC * sizeof(pq_recA), B.data(), H2Y_PQ_NREC * sizeof(pq_recB),
                                hipMemcpyHostToDevice));
     }
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_assumed, 2 * sizeof(assumed_stats)));
@@ -701,7 +702,7 @@ int h2y_matrix_convert(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3
     io.tmp_cr = d_out444[2];
     ctx->h_frames[0] = io;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frames, ctx->h_frames, sizeof(frame_io), hipMemcpyHostToDevice, ctx->stream));
-    const int grid = grid_for(ctx, g.chunks);
+    const int grid = grid_for(ctx, d, H2Y_OUT_444TMP, pp.mode, g.narrow, g.chunks);
     rc = ensure(ctx, ctx->d_partial, ctx->partial_cap, (size_t)grid * 6 * sizeof(float));
     if (rc) return rc;
     fused_args a;
@@ -717,7 +718,7 @@ int h2y_matrix_convert(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3
     a.partial = ctx->d_partial;
     a.assumed = ctx->d_assumed;
     a.pp = pp;
-    HIP_TRY(ctx, h2y_launch_fused(in_kind_of(d), H2Y_OUT_444TMP, g.narrow, grid, ctx->stream, a));
+    HIP_TRY(ctx, h2y_launch_fused(in_kind_of(d), H2Y_OUT_444TMP, pp.mode, g.narrow, grid, ctx->stream, a));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return H2Y_OK;
 }

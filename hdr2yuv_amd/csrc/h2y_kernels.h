@@ -8,7 +8,12 @@
 
 #include "h2y_math.h"
 
+#ifndef H2Y_FUSED_THREADS
 #define H2Y_FUSED_THREADS 512
+#endif
+#ifndef H2Y_FUSED_MINWAVES
+#define H2Y_FUSED_MINWAVES 4 /* waves per SIMD the fused kernel is register-budgeted for: 2 blocks of 512 per CU */
+#endif
 
 enum { H2Y_IN_F32 = 0, H2Y_IN_F16 = 1, H2Y_IN_U16 = 2 };
 enum { H2Y_OUT_420BOX = 0, H2Y_OUT_444 = 1, H2Y_OUT_444TMP = 2 };
@@ -78,7 +83,8 @@ struct fir_args {
     h2y::pix_params pp;
 };
 
-hipError_t h2y_launch_fused(int in_kind, int out_kind, bool narrow, int grid, hipStream_t st, const fused_args &a);
+int h2y_fused_blocks_per_cu(int in_kind, int out_kind, int mode, bool narrow);
+hipError_t h2y_launch_fused(int in_kind, int out_kind, int mode, bool narrow, int grid, hipStream_t st, const fused_args &a);
 hipError_t h2y_launch_stats(int in_kind, int grid, hipStream_t st, const stats_args &a);
 hipError_t h2y_launch_stats_final(int n_frames, hipStream_t st, const final_args &a);
 hipError_t h2y_launch_fir420(hipStream_t st, const fir_args &a);

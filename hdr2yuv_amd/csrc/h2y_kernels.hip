@@ -44,7 +44,20 @@ __device__ __forceinline__ float wave_max(float v)
 }
 
 /* pic_stats update, common.cpp:126-127: "s < min ? s : min" -- a NaN never
- * wins, which fminf/fmaxf reproduce (they return the non-NaN operand). */
+ * wins, which v_min/v_max reproduce (they return the non-NaN operand).
+ * v_min3/v_max3 fold two new samples per instruction. */
+__device__ __forceinline__ float min3f(float a, float b, float c)
+{
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float max3f(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 struct mm6 {
     float lo[3], hi[3];
     __device__ __forceinline__ void reset()
@@ -57,8 +70,13 @@ struct mm6 {
     }
     __device__ __forceinline__ void add(int c, float s)
     {
-        lo[c] = fminf(lo[c], s);
-        hi[c] = fmaxf(hi[c], s);
+        lo[c] = min3f(lo[c], s, s);
+        hi[c] = max3f(hi[c], s, s);
+    }
+    __device__ __forceinline__ void add2(int c, float s, float t)
+    {
+        lo[c] = min3f(lo[c], s, t);
+        hi[c] = max3f(hi[c], s, t);
     }
 };
 
@@ -124,32 +142,56 @@ template <> struct in_traits<H2Y_IN_U16> {
 };
 
 /* ---- one pixel: normalise -> PQ -> scale -> matrix ---------------------- */
-__device__ __forceinline__ float pq_sample(float x, const pq_recA *sA, const pq_recB *sB)
+
+/* Careful tier for one pixel: the reference's operations one by one (double-
+ * double pow in place of libm's, IEEE divisions).  Out of line: about one
+ * pixel in 10^4 comes here. */
+struct ycc {
+    uint32_t y, cb, cr;
+};
+template <int MODE>
+__device__ __attribute__((noinline)) ycc pixel_careful(const pix_params *spp /* block's copy in LDS */, float G, float B, float R)
 {
-    bool slow;
-    float v = pq_fast(x, sA, sB, &slow);
-    if (__builtin_expect(slow, 0)) v = pq_slow(x);
-    return v;
+    const pix_params &pp = *spp;
+    ycc o;
+    uint32_t &Y = o.y, &Cb = o.cb, &Cr = o.cr;
+    if (pp.convert_transfer) {
+        G = pix_scale(pq_slow(G), pp.mulY, pp.addY);
+        B = pix_scale(pq_slow(B), pp.mulC, pp.addC);
+        R = pix_scale(pq_slow(R), pp.mulC, pp.addC);
+    }
+    bool dummy;
+    pix_matrix<MODE, true>(pp, G, B, R, Y, Cb, Cr, &dummy);
+    return o;
 }
 
-__device__ __forceinline__ void pixel(const pix_params &pp, const pq_recA *sA, const pq_recB *sB, float G, float B,
-                                      float R, uint32_t &Y, uint32_t &Cb, uint32_t &Cr)
+template <int MODE>
+__device__ __forceinline__ void pixel(const pix_params &pp, const pix_params *spp, const pq_recA *sA, const pq_recB *sB,
+                                      float G, float B, float R, uint32_t &Y, uint32_t &Cb, uint32_t &Cr)
 {
-    if (pp.convert_transfer) {
-        if (!pp.norm_identity) {
-            /* convert.cpp:1017-1019, binary32 subtract and IEEE divide */
-            G = (G - pp.offset[0]) / pp.range[0];
-            B = (B - pp.offset[1]) / pp.range[1];
-            R = (R - pp.offset[2]) / pp.range[2];
-        }
-        G = pq_sample(G, sA, sB);
-        B = pq_sample(B, sA, sB);
-        R = pq_sample(R, sA, sB);
-        G = pix_scale(G, pp.mulY, pp.addY, pp.scale_mode);
-        B = pix_scale(B, pp.mulC, pp.addC, pp.scale_mode);
-        R = pix_scale(R, pp.mulC, pp.addC, pp.scale_mode);
+    if (pp.convert_transfer && !pp.norm_identity) {
+        /* convert.cpp:1017-1019, binary32 subtract and IEEE divide */
+        G = (G - pp.offset[0]) / pp.range[0];
+        B = (B - pp.offset[1]) / pp.range[1];
+        R = (R - pp.offset[2]) / pp.range[2];
     }
-    pix_matrix(pp, G, B, R, Y, Cb, Cr);
+    float g = G, b = B, r = R;
+    bool unsure = false;
+    if (pp.convert_transfer) {
+        bool sg, sb, sr;
+        g = pix_scale(pq_fast(G, sA, sB, &sg), pp.mulY, pp.addY);
+        b = pix_scale(pq_fast(B, sA, sB, &sb), pp.mulC, pp.addC);
+        r = pix_scale(pq_fast(R, sA, sB, &sr), pp.mulC, pp.addC);
+        unsure = sg | sb | sr;
+    }
+    bool um;
+    pix_matrix<MODE, false>(pp, g, b, r, Y, Cb, Cr, &um);
+    if (__builtin_expect(unsure | um, 0)) {
+        const ycc o = pixel_careful<MODE>(spp, G, B, R);
+        Y = o.y;
+        Cb = o.cb;
+        Cr = o.cr;
+    }
 }
 
 /* convert.cpp:939-940: range = ceiling - floor (int), offset = floor, as float */
@@ -181,6 +223,13 @@ __device__ __forceinline__ uint32_t udiv_magic(uint32_t n, uint32_t d, uint32_t 
     return q;
 }
 
+__device__ __forceinline__ void stage_table(const void *table, pq_recA *s_tab)
+{
+    const uint4 *g = reinterpret_cast<const uint4 *>(table);
+    uint4 *l = reinterpret_cast<uint4 *>(s_tab);
+    for (int i = threadIdx.x; i < 2 * H2Y_PQ_NREC; i += H2Y_FUSED_THREADS) l[i] = g[i];
+}
+
 /*
  * k_fused: one thread = 4 columns x 2 rows of one frame.
  *
@@ -198,27 +247,23 @@ __device__ __forceinline__ uint32_t udiv_magic(uint32_t n, uint32_t d, uint32_t 
  *   H2Y_OUT_444     Y, Cb, Cr final, full resolution
  *   H2Y_OUT_444TMP  Y final; Cb/Cr = matrix_convert() output (NOT yet
  *                   range-clamped) into scratch planes for k_fir420
+ * MODE: H2Y_MODE_YCBCR / H2Y_MODE_YDZDX compiled in, or H2Y_MODE_RUNTIME.
  */
-template <int IN_KIND, int OUT_KIND>
-__global__ __launch_bounds__(H2Y_FUSED_THREADS) void k_fused(fused_args a)
+template <int IN_KIND, int OUT_KIND, int MODE>
+__global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused(fused_args a)
 {
-    __shared__ pq_recA sA[H2Y_PQ_NSEG];
-    __shared__ pq_recB sB[H2Y_PQ_NSEG];
+    __shared__ pq_recA s_tab[2 * H2Y_PQ_NREC]; /* A records, then B records */
+    const pq_recA *sA = s_tab;
+    const pq_recB *sB = reinterpret_cast<const pq_recB *>(s_tab + H2Y_PQ_NREC);
     __shared__ float s_red[(H2Y_FUSED_THREADS / WAVE) * 6];
 
-    if (a.pp.convert_transfer) {
-        const uint4 *gA = reinterpret_cast<const uint4 *>(a.table);
-        const uint4 *gB = gA + H2Y_PQ_NSEG;
-        uint4 *lA = reinterpret_cast<uint4 *>(sA), *lB = reinterpret_cast<uint4 *>(sB);
-        for (int i = threadIdx.x; i < H2Y_PQ_NSEG; i += H2Y_FUSED_THREADS) {
-            lA[i] = gA[i];
-            lB[i] = gB[i];
-        }
-    }
-    __syncthreads();
-
+    __shared__ pix_params s_pp;
+    if (a.pp.convert_transfer) stage_table(a.table, s_tab);
     typedef in_traits<IN_KIND> IN;
     const pix_params pp = with_assumed(a.pp, a.assumed);
+    if (threadIdx.x == 0) s_pp = pp;
+    __syncthreads();
+
     const uint32_t W = a.width, H = a.height, WQ = a.wq;
     const size_t npix = (size_t)W * H;
     const uint32_t G = gridDim.x;
@@ -248,56 +293,59 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS) void k_fused(fused_args a)
             IN::load4(io.in[2], i1, r1);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                mm.add(0, g0[j]); mm.add(1, b0[j]); mm.add(2, r0[j]);
-                mm.add(0, g1[j]); mm.add(1, b1[j]); mm.add(2, r1[j]);
+                mm.add2(0, g0[j], g1[j]);
+                mm.add2(1, b0[j], b1[j]);
+                mm.add2(2, r0[j], r1[j]);
             }
 
-            uint32_t Y0[4], Y1[4], Cb0[4], Cb1[4], Cr0[4], Cr1[4];
+            /* two 2x2 blocks, one after the other, results packed as soon as they exist */
+            uint32_t yp0[2], yp1[2], cbp0[2], cbp1[2], crp0[2], crp1[2];
+            uint32_t cb_box = 0, cr_box = 0;
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                pixel(pp, sA, sB, g0[j], b0[j], r0[j], Y0[j], Cb0[j], Cr0[j]);
-                pixel(pp, sA, sB, g1[j], b1[j], r1[j], Y1[j], Cb1[j], Cr1[j]);
+            for (int jb = 0; jb < 2; jb++) {
+                uint32_t Y[4], Cb[4], Cr[4];
+                pixel<MODE>(pp, &s_pp, sA, sB, g0[2 * jb], b0[2 * jb], r0[2 * jb], Y[0], Cb[0], Cr[0]);
+                pixel<MODE>(pp, &s_pp, sA, sB, g0[2 * jb + 1], b0[2 * jb + 1], r0[2 * jb + 1], Y[1], Cb[1], Cr[1]);
+                pixel<MODE>(pp, &s_pp, sA, sB, g1[2 * jb], b1[2 * jb], r1[2 * jb], Y[2], Cb[2], Cr[2]);
+                pixel<MODE>(pp, &s_pp, sA, sB, g1[2 * jb + 1], b1[2 * jb + 1], r1[2 * jb + 1], Y[3], Cb[3], Cr[3]);
+                yp0[jb] = pix_yuv_clamp(pp, Y[0], false) | (pix_yuv_clamp(pp, Y[1], false) << 16);
+                yp1[jb] = pix_yuv_clamp(pp, Y[2], false) | (pix_yuv_clamp(pp, Y[3], false) << 16);
+                if (OUT_KIND == H2Y_OUT_420BOX) {
+                    /* convert.cpp:157-160: (a+b+c+d)/4, unsigned truncation; then write_yuv's clamp */
+                    uint32_t cb = pix_yuv_clamp(pp, (Cb[0] + Cb[1] + Cb[2] + Cb[3]) >> 2, true);
+                    uint32_t cr = pix_yuv_clamp(pp, (Cr[0] + Cr[1] + Cr[2] + Cr[3]) >> 2, true);
+                    cb_box |= cb << (16 * jb);
+                    cr_box |= cr << (16 * jb);
+                } else {
+                    if (OUT_KIND == H2Y_OUT_444) {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            Cb[q] = pix_yuv_clamp(pp, Cb[q], true);
+                            Cr[q] = pix_yuv_clamp(pp, Cr[q], true);
+                        }
+                    }
+                    cbp0[jb] = Cb[0] | (Cb[1] << 16); cbp1[jb] = Cb[2] | (Cb[3] << 16);
+                    crp0[jb] = Cr[0] | (Cr[1] << 16); crp1[jb] = Cr[2] | (Cr[3] << 16);
+                }
             }
 
             uint16_t *Yp = io.out;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                Y0[j] = pix_yuv_clamp(pp, Y0[j], false);
-                Y1[j] = pix_yuv_clamp(pp, Y1[j], false);
-            }
-            *reinterpret_cast<uint2 *>(Yp + i0) = make_uint2(Y0[0] | (Y0[1] << 16), Y0[2] | (Y0[3] << 16));
-            if (row1) *reinterpret_cast<uint2 *>(Yp + i1) = make_uint2(Y1[0] | (Y1[1] << 16), Y1[2] | (Y1[3] << 16));
-
+            *reinterpret_cast<uint2 *>(Yp + i0) = make_uint2(yp0[0], yp0[1]);
+            if (row1) *reinterpret_cast<uint2 *>(Yp + i1) = make_uint2(yp1[0], yp1[1]);
             if (OUT_KIND == H2Y_OUT_420BOX) {
-                /* convert.cpp:157-160: (a+b+c+d)/4, unsigned truncation */
                 const uint32_t wc = W >> 1;
                 const size_t ic = (size_t)rp * wc + (x >> 1);
-                uint32_t cb_a = (Cb0[0] + Cb0[1] + Cb1[0] + Cb1[1]) >> 2, cb_b = (Cb0[2] + Cb0[3] + Cb1[2] + Cb1[3]) >> 2;
-                uint32_t cr_a = (Cr0[0] + Cr0[1] + Cr1[0] + Cr1[1]) >> 2, cr_b = (Cr0[2] + Cr0[3] + Cr1[2] + Cr1[3]) >> 2;
-                cb_a = pix_yuv_clamp(pp, cb_a, true); cb_b = pix_yuv_clamp(pp, cb_b, true);
-                cr_a = pix_yuv_clamp(pp, cr_a, true); cr_b = pix_yuv_clamp(pp, cr_b, true);
                 uint16_t *Cbp = io.out + npix, *Crp = Cbp + (size_t)wc * (H >> 1);
-                *reinterpret_cast<uint32_t *>(Cbp + ic) = cb_a | (cb_b << 16);
-                *reinterpret_cast<uint32_t *>(Crp + ic) = cr_a | (cr_b << 16);
+                *reinterpret_cast<uint32_t *>(Cbp + ic) = cb_box;
+                *reinterpret_cast<uint32_t *>(Crp + ic) = cr_box;
             } else {
-                uint16_t *Cbp, *Crp;
-                if (OUT_KIND == H2Y_OUT_444) {
-                    Cbp = io.out + npix;
-                    Crp = Cbp + npix;
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        Cb0[j] = pix_yuv_clamp(pp, Cb0[j], true); Cb1[j] = pix_yuv_clamp(pp, Cb1[j], true);
-                        Cr0[j] = pix_yuv_clamp(pp, Cr0[j], true); Cr1[j] = pix_yuv_clamp(pp, Cr1[j], true);
-                    }
-                } else {
-                    Cbp = io.tmp_cb;
-                    Crp = io.tmp_cr;
-                }
-                *reinterpret_cast<uint2 *>(Cbp + i0) = make_uint2(Cb0[0] | (Cb0[1] << 16), Cb0[2] | (Cb0[3] << 16));
-                *reinterpret_cast<uint2 *>(Crp + i0) = make_uint2(Cr0[0] | (Cr0[1] << 16), Cr0[2] | (Cr0[3] << 16));
+                uint16_t *Cbp = OUT_KIND == H2Y_OUT_444 ? io.out + npix : io.tmp_cb;
+                uint16_t *Crp = OUT_KIND == H2Y_OUT_444 ? io.out + 2 * npix : io.tmp_cr;
+                *reinterpret_cast<uint2 *>(Cbp + i0) = make_uint2(cbp0[0], cbp0[1]);
+                *reinterpret_cast<uint2 *>(Crp + i0) = make_uint2(crp0[0], crp0[1]);
                 if (row1) {
-                    *reinterpret_cast<uint2 *>(Cbp + i1) = make_uint2(Cb1[0] | (Cb1[1] << 16), Cb1[2] | (Cb1[3] << 16));
-                    *reinterpret_cast<uint2 *>(Crp + i1) = make_uint2(Cr1[0] | (Cr1[1] << 16), Cr1[2] | (Cr1[3] << 16));
+                    *reinterpret_cast<uint2 *>(Cbp + i1) = make_uint2(cbp1[0], cbp1[1]);
+                    *reinterpret_cast<uint2 *>(Crp + i1) = make_uint2(crp1[0], crp1[1]);
                 }
             }
         }
@@ -313,21 +361,16 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS) void k_fused(fused_args a)
 template <int IN_KIND, int OUT_KIND>
 __global__ __launch_bounds__(H2Y_FUSED_THREADS) void k_fused_narrow(fused_args a)
 {
-    __shared__ pq_recA sA[H2Y_PQ_NSEG];
-    __shared__ pq_recB sB[H2Y_PQ_NSEG];
+    __shared__ pq_recA s_tab[2 * H2Y_PQ_NREC]; /* A records, then B records */
+    const pq_recA *sA = s_tab;
+    const pq_recB *sB = reinterpret_cast<const pq_recB *>(s_tab + H2Y_PQ_NREC);
     __shared__ float s_red[(H2Y_FUSED_THREADS / WAVE) * 6];
-    if (a.pp.convert_transfer) {
-        const uint4 *gA = reinterpret_cast<const uint4 *>(a.table);
-        const uint4 *gB = gA + H2Y_PQ_NSEG;
-        uint4 *lA = reinterpret_cast<uint4 *>(sA), *lB = reinterpret_cast<uint4 *>(sB);
-        for (int i = threadIdx.x; i < H2Y_PQ_NSEG; i += H2Y_FUSED_THREADS) {
-            lA[i] = gA[i];
-            lB[i] = gB[i];
-        }
-    }
-    __syncthreads();
+    __shared__ pix_params s_pp;
+    if (a.pp.convert_transfer) stage_table(a.table, s_tab);
     typedef in_traits<IN_KIND> IN;
     const pix_params pp = with_assumed(a.pp, a.assumed);
+    if (threadIdx.x == 0) s_pp = pp;
+    __syncthreads();
     const uint32_t W = a.width, H = a.height;
     const size_t npix = (size_t)W * H;
     const uint32_t G = gridDim.x;
@@ -350,7 +393,7 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS) void k_fused_narrow(fused_args a
                 float g = IN::load1(io.in[0], i), b = IN::load1(io.in[1], i), r = IN::load1(io.in[2], i);
                 mm.add(0, g); mm.add(1, b); mm.add(2, r);
                 uint32_t Y, Cb, Cr;
-                pixel(pp, sA, sB, g, b, r, Y, Cb, Cr);
+                pixel<H2Y_MODE_RUNTIME>(pp, &s_pp, sA, sB, g, b, r, Y, Cb, Cr);
                 io.out[i] = (uint16_t)pix_yuv_clamp(pp, Y, false);
                 if (OUT_KIND == H2Y_OUT_444) {
                     io.out[npix + i] = (uint16_t)pix_yuv_clamp(pp, Cb, true);
@@ -380,8 +423,8 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS) void k_stats(stats_args a)
         for (int c = 0; c < 3; c++) {
             float v[4];
             IN::load4(a.in[c], i * 4, v);
-#pragma unroll
-            for (int j = 0; j < 4; j++) mm.add(c, v[j]);
+            mm.add2(c, v[0], v[1]);
+            mm.add2(c, v[2], v[3]);
         }
     }
     for (size_t i = n4 * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
@@ -514,26 +557,49 @@ __global__ __launch_bounds__(256) void k_fir420(fir_args a)
 }
 
 /* ---- launch helpers (called from h2y_api.hip) --------------------------- */
-template <int IN_KIND>
-static hipError_t launch_fused_in(int out_kind, bool narrow, dim3 grid, hipStream_t st, const fused_args &a)
-{
-    dim3 blk(H2Y_FUSED_THREADS);
-    if (narrow) {
-        if (out_kind == H2Y_OUT_444) hipLaunchKernelGGL((k_fused_narrow<IN_KIND, H2Y_OUT_444>), grid, blk, 0, st, a);
-        else hipLaunchKernelGGL((k_fused_narrow<IN_KIND, H2Y_OUT_444TMP>), grid, blk, 0, st, a);
-    } else if (out_kind == H2Y_OUT_420BOX) hipLaunchKernelGGL((k_fused<IN_KIND, H2Y_OUT_420BOX>), grid, blk, 0, st, a);
-    else if (out_kind == H2Y_OUT_444) hipLaunchKernelGGL((k_fused<IN_KIND, H2Y_OUT_444>), grid, blk, 0, st, a);
-    else hipLaunchKernelGGL((k_fused<IN_KIND, H2Y_OUT_444TMP>), grid, blk, 0, st, a);
-    return hipGetLastError();
-}
+typedef void (*fused_fn)(fused_args);
 
-hipError_t h2y_launch_fused(int in_kind, int out_kind, bool narrow, int grid, hipStream_t st, const fused_args &a)
+template <int IN_KIND, int OUT_KIND> static fused_fn pick_mode(int mode)
+{
+    switch (mode) {
+    case H2Y_MODE_YCBCR: return k_fused<IN_KIND, OUT_KIND, H2Y_MODE_YCBCR>;
+    case H2Y_MODE_YDZDX: return k_fused<IN_KIND, OUT_KIND, H2Y_MODE_YDZDX>;
+    default: return k_fused<IN_KIND, OUT_KIND, H2Y_MODE_RUNTIME>;
+    }
+}
+template <int IN_KIND> static fused_fn pick_out(int out_kind, int mode, bool narrow)
+{
+    if (narrow) return out_kind == H2Y_OUT_444 ? k_fused_narrow<IN_KIND, H2Y_OUT_444> : k_fused_narrow<IN_KIND, H2Y_OUT_444TMP>;
+    switch (out_kind) {
+    case H2Y_OUT_420BOX: return pick_mode<IN_KIND, H2Y_OUT_420BOX>(mode);
+    case H2Y_OUT_444: return pick_mode<IN_KIND, H2Y_OUT_444>(mode);
+    default: return pick_mode<IN_KIND, H2Y_OUT_444TMP>(mode);
+    }
+}
+static fused_fn pick_fused(int in_kind, int out_kind, int mode, bool narrow)
 {
     switch (in_kind) {
-    case H2Y_IN_F32: return launch_fused_in<H2Y_IN_F32>(out_kind, narrow, dim3(grid), st, a);
-    case H2Y_IN_F16: return launch_fused_in<H2Y_IN_F16>(out_kind, narrow, dim3(grid), st, a);
-    default: return launch_fused_in<H2Y_IN_U16>(out_kind, narrow, dim3(grid), st, a);
+    case H2Y_IN_F32: return pick_out<H2Y_IN_F32>(out_kind, mode, narrow);
+    case H2Y_IN_F16: return pick_out<H2Y_IN_F16>(out_kind, mode, narrow);
+    default: return pick_out<H2Y_IN_U16>(out_kind, mode, narrow);
     }
+}
+
+/* resident blocks per CU for this variant (the grid is sized to exactly fill the chip) */
+int h2y_fused_blocks_per_cu(int in_kind, int out_kind, int mode, bool narrow)
+{
+    int nb = 0;
+    fused_fn fn = pick_fused(in_kind, out_kind, mode, narrow);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(fn), H2Y_FUSED_THREADS, 0) != hipSuccess || nb < 1)
+        nb = 1;
+    return nb;
+}
+
+hipError_t h2y_launch_fused(int in_kind, int out_kind, int mode, bool narrow, int grid, hipStream_t st, const fused_args &a)
+{
+    fused_fn fn = pick_fused(in_kind, out_kind, mode, narrow);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(H2Y_FUSED_THREADS), 0, st, a);
+    return hipGetLastError();
 }
 
 hipError_t h2y_launch_stats(int in_kind, int grid, hipStream_t st, const stats_args &a)

@@ -249,63 +249,102 @@ H2Y_FN dd pq_exact_dd(dd x)
  * Segment index = (float bits >> 17) - H2Y_PQ_SEG_BASE: exponent and top 6
  * mantissa bits, for x in [2^H2Y_PQ_EMIN, 2).  Two 16-byte records per
  * segment, kept in two arrays so that neighbouring segments fall in
- * neighbouring LDS bank groups:
+ * neighbouring LDS bank groups (one ds_read_b128 each):
  *     A[i] = { c0, c1 }           (2 x binary64)
  *     B[i] = { c2, c3|c4 }        (binary64, 2 x binary32)
- * value = c0 + u(c1 + u(c2 + u(c3 + u c4))),  u in [-1,1) across the segment.
+ * value = c0 + u(c1 + u(c2 + u(c3 + u c4))), u = offset of the mantissa from
+ * the segment centre, in [-2^-7, 2^-7) (units of the binade's leading bit).
+ * Entry H2Y_PQ_NSEG is a sentinel every out-of-table input is steered to: its
+ * value sits exactly on a float rounding tie, so the ambiguity test below
+ * sends the sample to the slow tier without a separate range check.
  * ---------------------------------------------------------------------- */
 #define H2Y_PQ_EMIN (-24)
 #define H2Y_PQ_SEG_BITS 6
 #define H2Y_PQ_SEG_PER_BINADE (1 << H2Y_PQ_SEG_BITS)
 #define H2Y_PQ_NBINADES (1 - H2Y_PQ_EMIN) /* exponents EMIN..0 */
 #define H2Y_PQ_NSEG (H2Y_PQ_NBINADES * H2Y_PQ_SEG_PER_BINADE)
+#define H2Y_PQ_NREC (H2Y_PQ_NSEG + 1)
 #define H2Y_PQ_LOW_BITS (23 - H2Y_PQ_SEG_BITS)
 #define H2Y_PQ_SEG_BASE ((uint32_t)(127 + H2Y_PQ_EMIN) << H2Y_PQ_SEG_BITS)
-#define H2Y_PQ_TABLE_BYTES (H2Y_PQ_NSEG * 32)
+#define H2Y_PQ_TABLE_BYTES (H2Y_PQ_NREC * 32)
 
 /* A double's low 29 mantissa bits decide its rounding to float; the tie is
  * at 2^28.  The fast value is trusted when those bits are at least this far
  * (in units of the double's last place) from the tie: 2^12 ulp = 2^-40
- * relative at worst (mantissa in [1,2)), ~8x the measured fast-tier error. */
+ * relative at worst (mantissa in [1,2)), ~6x the measured fast-tier error
+ * (tools/pq_check: max 689 ulp over every float in the table's domain). */
 #define H2Y_PQ_AMBIG_ULPS 4096u
 
-struct pq_recA {
+struct alignas(16) pq_recA {
     double c0, c1;
 };
-struct pq_recB {
+struct alignas(16) pq_recB {
     double c2;
     float c3, c4;
 };
+
+/* the polynomial itself (shared with tools/pq_check.cpp) */
+H2Y_FN double pq_poly(uint32_t bits, const pq_recA &a, const pq_recB &b)
+{
+    /* 1.0 + low mantissa bits, minus the segment centre 1 + 2^-7: exact in binary32 */
+    float f = bits2f((bits & ((1u << H2Y_PQ_LOW_BITS) - 1u)) | 0x3F800000u);
+    float u = f - (1.0f + 1.0f / (float)(2 << H2Y_PQ_SEG_BITS));
+    float p = __builtin_fmaf(b.c4, u, b.c3);
+    double ud = (double)u;
+    double v = __builtin_fma((double)p, ud, b.c2);
+    v = __builtin_fma(v, ud, a.c1);
+    return __builtin_fma(v, ud, a.c0);
+}
+/* byte offset of the segment's records; out-of-table inputs (0, tiny, >= 2,
+ * negative, NaN) all wrap above the table and are clamped to the sentinel */
+H2Y_FN uint32_t pq_rec_offset(uint32_t bits)
+{
+    uint32_t t = bits - (H2Y_PQ_SEG_BASE << H2Y_PQ_LOW_BITS);
+    uint32_t off = (t >> (H2Y_PQ_LOW_BITS - 4)) & ~15u;
+    return off < (uint32_t)H2Y_PQ_NSEG * 16u ? off : (uint32_t)H2Y_PQ_NSEG * 16u;
+}
+H2Y_FN bool pq_ambiguous(double v)
+{
+    uint32_t lo = (uint32_t)d2bits(v);
+    uint32_t dist = (lo + (H2Y_PQ_AMBIG_ULPS - 0x10000000u)) & 0x1FFFFFFFu;
+    return dist < 2u * H2Y_PQ_AMBIG_ULPS;
+}
 
 /* Fast tier.  Returns the float value; *slow is set when the caller must use
  * pq_slow(x) instead (x outside the table, or rounding too close to call). */
 H2Y_FN float pq_fast(float x, const pq_recA *__restrict__ A, const pq_recB *__restrict__ B, bool *slow)
 {
-    uint32_t bits = f2bits(x);
-    uint32_t t = bits - (H2Y_PQ_SEG_BASE << H2Y_PQ_LOW_BITS);
-    bool inrange = t < ((uint32_t)H2Y_PQ_NSEG << H2Y_PQ_LOW_BITS); /* also rejects negatives, 0, NaN */
-    uint32_t idx = inrange ? (t >> H2Y_PQ_LOW_BITS) : 0u;
-    /* u = 2*frac - 1 over the segment, exact in binary32 */
-    float f = bits2f((bits & ((1u << H2Y_PQ_LOW_BITS) - 1u)) | 0x3F800000u);
-    float u = __builtin_fmaf(f, (float)(1 << (H2Y_PQ_SEG_BITS + 1)), -(float)((1 << (H2Y_PQ_SEG_BITS + 1)) + 1));
-    pq_recA a = A[idx];
-    pq_recB b = B[idx];
-    float p = __builtin_fmaf(b.c4, u, b.c3);
-    double ud = (double)u;
-    double v = __builtin_fma((double)p, ud, b.c2);
-    v = __builtin_fma(v, ud, a.c1);
-    v = __builtin_fma(v, ud, a.c0);
-    uint32_t lo = (uint32_t)d2bits(v);
-    uint32_t dist = (lo + (H2Y_PQ_AMBIG_ULPS - 0x10000000u)) & 0x1FFFFFFFu;
-    *slow = !inrange || dist < 2u * H2Y_PQ_AMBIG_ULPS;
+    const uint32_t bits = f2bits(x);
+    const uint32_t off = pq_rec_offset(bits);
+    /* (B is A + H2Y_PQ_NREC records in the kernels' LDS image: one address register,
+     * the second load uses the instruction's immediate offset) */
+    /* one 16-byte load per record (ds_read_b128 when the table is in LDS) */
+#if defined(__clang__)
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+#else
+    struct alignas(16) u32x4 {
+        uint32_t x, y, z, w;
+    };
+#endif
+    const u32x4 ra = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(A) + off);
+    const u32x4 rb = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(B) + off);
+    pq_recA a;
+    pq_recB b;
+    a.c0 = bits2d((uint64_t)ra.x | ((uint64_t)ra.y << 32));
+    a.c1 = bits2d((uint64_t)ra.z | ((uint64_t)ra.w << 32));
+    b.c2 = bits2d((uint64_t)rb.x | ((uint64_t)rb.y << 32));
+    b.c3 = bits2f(rb.z);
+    b.c4 = bits2f(rb.w);
+    const double v = pq_poly(bits, a, b);
+    *slow = pq_ambiguous(v);
     return (float)v;
 }
 
 /* Host-side table builder (context creation).  Per segment: interpolate the
  * double-double PQ at five near-Chebyshev nodes (Newton divided differences
- * in double-double), expand to monomials in u, round c0..c2 to binary64 and
- * c3,c4 to binary32.  Pure IEEE double arithmetic: the same table on every
- * host, no libm involved. */
+ * in double-double), expand to monomials, round c0..c2 to binary64 and c3,c4
+ * to binary32.  Pure IEEE double arithmetic: the same table on every host, no
+ * libm involved.  A and B each hold H2Y_PQ_NREC records. */
 inline void pq_build_table(pq_recA *A, pq_recB *B)
 {
     const double un[5] = {-0.9510565162951535, -0.5877852522924731, 0.0, 0.5877852522924731, 0.9510565162951535};
@@ -317,17 +356,16 @@ inline void pq_build_table(pq_recA *A, pq_recB *B)
         double half = scale * (0.5 / H2Y_PQ_SEG_PER_BINADE);            /* exact */
         dd dv[5];
         for (int j = 0; j < 5; j++) dv[j] = pq_exact_dd(dd_add_d(two_prod(un[j], half), mid));
-        /* divided differences in u */
+        /* divided differences in the normalised variable w in [-1,1] */
         for (int lvl = 1; lvl < 5; lvl++)
             for (int j = 4; j >= lvl; j--) {
                 dd num = dd_add(dv[j], dd{-dv[j - 1].hi, -dv[j - 1].lo});
                 dv[j] = dd_div(num, dd{un[j] - un[j - lvl], 0.0});
             }
-        /* p(u) = dv0 + (u-u0)(dv1 + (u-u1)(dv2 + (u-u2)(dv3 + (u-u3) dv4))) -> monomials */
+        /* p(w) = dv0 + (w-w0)(dv1 + (w-w1)(dv2 + (w-w2)(dv3 + (w-w3) dv4))) -> monomials */
         dd c[5] = {dv[4], {0, 0}, {0, 0}, {0, 0}, {0, 0}};
         int deg = 0;
         for (int j = 3; j >= 0; j--) {
-            /* c(u) <- c(u) * (u - u_j) + dv[j] */
             dd nc[5] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
             for (int k = 0; k <= deg; k++) {
                 nc[k + 1] = dd_add(nc[k + 1], c[k]);
@@ -337,130 +375,188 @@ inline void pq_build_table(pq_recA *A, pq_recB *B)
             deg++;
             for (int k = 0; k <= deg; k++) c[k] = nc[k];
         }
+        /* the kernel's u is w / 2^(SEG_BITS+1): rescale by exact powers of two */
+        const double r = (double)(2 << H2Y_PQ_SEG_BITS);
         A[i].c0 = c[0].hi;
-        A[i].c1 = c[1].hi;
-        B[i].c2 = c[2].hi;
-        B[i].c3 = (float)c[3].hi;
-        B[i].c4 = (float)c[4].hi;
+        A[i].c1 = c[1].hi * r;
+        B[i].c2 = c[2].hi * r * r;
+        B[i].c3 = (float)(c[3].hi * r * r * r);
+        B[i].c4 = (float)(c[4].hi * r * r * r * r);
     }
+    /* sentinel: 1 + 2^-24 is exactly half way between two floats */
+    A[H2Y_PQ_NSEG].c0 = 1.0 + 0x1p-24;
+    A[H2Y_PQ_NSEG].c1 = 0.0;
+    B[H2Y_PQ_NSEG].c2 = 0.0;
+    B[H2Y_PQ_NSEG].c3 = 0.0f;
+    B[H2Y_PQ_NSEG].c4 = 0.0f;
 }
 
 /* ------------------------------------------------------------------------
  * Per-frame constants handed to the kernels.
  * ---------------------------------------------------------------------- */
 enum : int { H2Y_MODE_IDENTITY = 0, H2Y_MODE_YDZDX = 1, H2Y_MODE_YCBCR = 2, H2Y_MODE_YPQRS = 3 };
-enum : int { H2Y_SCALE_NONE = 0, H2Y_SCALE_FULL = 1, H2Y_SCALE_GBR = 2, H2Y_SCALE_YCC = 3 };
 
 struct pix_params {
     /* matrix_convert */
-    int convert_transfer;  /* convert.cpp:930 */
-    int norm_identity;     /* offset 0 and range 1 for all three planes */
+    int convert_transfer;      /* convert.cpp:930 */
+    int norm_identity;         /* offset 0 and range 1 for all three planes */
     float offset[3], range[3]; /* convert.cpp:939-940 */
-    int scale_mode;        /* H2Y_SCALE_*, convert.cpp:1123-1145 */
-    float mulY, addY, mulC, addC; /* G: mulY/addY, B and R: mulC/addC */
-    int mode;              /* H2Y_MODE_*, convert.cpp:1159-1198 */
-    double kr, kg, kb;     /* luma weights as written in the reference */
-    double dcb, dcr;       /* chroma divisors */
+    float mulY, addY, mulC, addC; /* scale step convert.cpp:1123-1145; G: mulY/addY, B and R: mulC/addC */
+    int mode;                  /* H2Y_MODE_*, convert.cpp:1159-1198 */
+    double kr, kg, kb;         /* luma weights as written in the reference */
+    double dcb, dcr;           /* chroma divisors */
     double inv_dcb, inv_dcr;
-    float P, Q, RR, S;     /* convert.cpp:913-925 */
-    uint32_t half_m1;      /* clip->Half - 1, convert.cpp:1200 */
-    uint32_t maxCV;        /* tmp picture's, convert.cpp:1207 */
-    /* convert(): FIR clamp uses the tmp picture's maxCV as float */
-    float fir_max;
-    /* write_yuv, tiff.cpp:394,469-478 with the OUTPUT picture's limits */
+    float P, Q, RR, S;         /* convert.cpp:913-925 */
+    uint32_t half_m1;          /* clip->Half - 1, convert.cpp:1200 */
+    uint32_t maxCV;            /* tmp picture's, convert.cpp:1207 */
+    float fir_max;             /* convert(): FIR clamp, (float)maxCV of the tmp picture */
+    /* write_yuv, tiff.cpp:394,469-478 with the OUTPUT picture's limits
+     * (0..maxCV when the output is full range) */
     int down_shift;
-    int full_range;
-    uint32_t ylo, yhi, clo, chi, out_maxCV;
+    uint32_t ylo, yhi, clo, chi;
 };
 
-/* float -> unsigned int.  Pinned domain: finite 0 <= f < 2^32,
- * where this is C truncation.  Outside it the C cast is undefined; the
- * reference's x86-64 build takes the low word of a 64-bit cvttss2si, which
- * this follows for -2^31 < f < 0 (wraps high, later clamps to maxCV) and for
- * NaN (0); f >= 2^32 saturates here (documented, unpinned). */
-H2Y_FN uint32_t f2u_ref(float f)
+/* ---- conversions with the hardware's (defined) saturating behaviour --------
+ * C leaves float->int casts undefined outside the target range; the kernels
+ * use the gfx950 instructions directly (NaN -> 0, saturate at the ends) and
+ * the host mirror spells the same function out. */
+H2Y_FN int32_t sat_i32_f32(float f)
 {
-    if (f >= 0.0f) return f < 4294967296.0f ? (uint32_t)f : 0xFFFFFFFFu;
-    if (f > -2147483648.0f) return (uint32_t)(int32_t)f;
-    return f != f ? 0u : 0x80000000u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    int32_t r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(f));
+    return r;
+#else
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return 2147483647;
+    if (f <= -2147483648.0f) return (int32_t)0x80000000;
+    return (int32_t)f;
+#endif
 }
-/* double -> int32 truncation (cvttsd2si r32) */
-H2Y_FN int32_t d2i_ref(double v)
+H2Y_FN int32_t sat_i32_f64(double v)
 {
-    if (!(v > -2147483649.0 && v < 2147483648.0)) return (int32_t)0x80000000;
+#if defined(__HIP_DEVICE_COMPILE__)
+    int32_t r;
+    asm("v_cvt_i32_f64 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+#else
+    if (v != v) return 0;
+    if (v >= 2147483648.0) return 2147483647;
+    if (v <= -2147483648.0) return (int32_t)0x80000000;
     return (int32_t)v;
+#endif
+}
+/* x - floor(x), in [0,1) (v_fract_f64) */
+H2Y_FN double fract_f64(double v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fract(v);
+#else
+    double fr = v - __builtin_floor(v);
+    return fr >= 1.0 ? 0x1.fffffffffffffp-1 : fr;
+#endif
 }
 
-/* (int)(d / c + 0.5) exactly as IEEE division would give it, without the
- * division: q = d * (1/c) differs from d / c by at most 1 ulp, which can only
- * change the truncated integer if q + 0.5 sits within a few ulps of an
- * integer; in that (never yet observed) case do the real division. */
-H2Y_FN int32_t div_round_trunc(float df, double c, double inv_c)
+/* (unsigned int)f followed by the "> maxCV" clamp of convert.cpp:1207.
+ * Pinned domain: finite 0 <= f < 2^31, where this is C truncation.
+ * Outside it the C cast is undefined; the reference's x86-64 build takes the
+ * low word of a 64-bit cvttss2si: -1 < f < 0 gives 0, f <= -1 wraps to a huge
+ * unsigned value that the clamp turns into maxCV, NaN gives 0.  The signed
+ * saturating convert reproduces all of that: a negative integer read as
+ * unsigned is huge.  (f >= 2^31 saturates to maxCV here; unpinned.) */
+H2Y_FN uint32_t f2u_clamped(float f, uint32_t maxCV)
 {
-    double d = (double)df;
-    double q = d * inv_c + 0.5;
-    double n = __builtin_rint(q);
-    if (__builtin_fabs(q - n) < 0x1p-46 * (1.0 + __builtin_fabs(q))) q = d / c + 0.5;
-    return d2i_ref(q);
+    uint32_t u = (uint32_t)sat_i32_f32(f);
+    return u < maxCV ? u : maxCV;
+}
+/* (long)Cb + Half - 1, then the unsigned compare against maxCV (convert.cpp:
+ * 1200-1212): a negative sum wraps high and clamps to maxCV.
+ * 32-bit wrap-around gives the same result as the reference's 64-bit one for
+ * every int32 n (Half - 1 < 2^15). */
+H2Y_FN uint32_t chroma_clamped(int32_t n, uint32_t half_m1, uint32_t maxCV)
+{
+    uint32_t c = (uint32_t)n + half_m1;
+    return c < maxCV ? c : maxCV;
+}
+
+/* q = d * (1/c) + 0.5 (one fma) stands in for the reference's
+ * RN(RN(d/c) + 0.5); the two differ by at most a couple of ulps (< 2^-34 for
+ * |q| < 2^18), which can only change the truncated integer when q is that
+ * close to an integer.  *uncertain is set when the fractional part is below
+ * 2^-30 or above 1 - 2^-21 (test on the high word of fract(q)). */
+H2Y_FN int32_t div_round_trunc_fast(float df, double inv_c, bool *uncertain)
+{
+    double q = __builtin_fma((double)df, inv_c, 0.5);
+    uint32_t fh = (uint32_t)(d2bits(fract_f64(q)) >> 32);
+    *uncertain = (fh - 0x3E100000u) >= (0x3FEFFFFFu - 0x3E100000u);
+    return sat_i32_f64(q);
 }
 
 /* matrix_convert() from scaled code values to clamped 4:4:4 integers,
  * convert.cpp:1150-1221.  G,B,R are the float code values after the scale
- * step (or the raw samples when convert_transfer == 0). */
-H2Y_FN void pix_matrix(const pix_params &pp, float G, float B, float R, uint32_t &Yo, uint32_t &Cbo, uint32_t &Cro)
+ * step (or the raw samples when convert_transfer == 0).  MODE is one of
+ * H2Y_MODE_*; H2Y_MODE_RUNTIME reads pp.mode.  EXACT_DIV = true performs the
+ * reference's IEEE divisions (careful tier); false uses the reciprocal form
+ * and reports through *uncertain when that cannot be trusted. */
+#define H2Y_MODE_RUNTIME (-1)
+template <int MODE, bool EXACT_DIV>
+H2Y_FN void pix_matrix(const pix_params &pp, float G, float B, float R, uint32_t &Yo, uint32_t &Cbo, uint32_t &Cro,
+                       bool *uncertain)
 {
-    uint32_t Y;
-    int64_t Cb, Cr;
-    if (pp.mode == H2Y_MODE_IDENTITY) {
-        Y = f2u_ref(G);
-        Cb = (int64_t)f2u_ref(B);
-        Cr = (int64_t)f2u_ref(R);
-    } else {
-        if (pp.mode == H2Y_MODE_YCBCR) {
-            double yd = ((pp.kr * (double)R + pp.kg * (double)G) + pp.kb * (double)B) + 0.5;
-            float tmpF = (float)yd;
-            Y = f2u_ref(tmpF);
-            Cb = div_round_trunc(B - tmpF, pp.dcb, pp.inv_dcb);
-            Cr = div_round_trunc(R - tmpF, pp.dcr, pp.inv_dcr);
-        } else if (pp.mode == H2Y_MODE_YDZDX) {
-            Y = f2u_ref(G);
-            double hg = (double)(-G) / 2.0;
-            Cb = d2i_ref((hg + (double)B / 2.0) + 0.5);
-            Cr = d2i_ref((hg + (double)R / 2.0) + 0.5);
-        } else {
-            Y = f2u_ref(G);
-            Cb = d2i_ref((double)(pp.P * G + pp.Q * B) + 0.5);
-            Cr = d2i_ref((double)(pp.RR * R + pp.S * G) + 0.5);
-        }
-        Cb += (int64_t)pp.half_m1;
-        Cr += (int64_t)pp.half_m1;
+    const int mode = MODE == H2Y_MODE_RUNTIME ? pp.mode : MODE;
+    *uncertain = false;
+    if (mode == H2Y_MODE_IDENTITY) {
+        Yo = f2u_clamped(G, pp.maxCV);
+        Cbo = f2u_clamped(B, pp.maxCV);
+        Cro = f2u_clamped(R, pp.maxCV);
+        return;
     }
-    /* unsigned 64-bit compares: negatives wrap and clamp high */
-    uint64_t y64 = Y, cb64 = (uint64_t)Cb, cr64 = (uint64_t)Cr;
-    Yo = y64 > pp.maxCV ? pp.maxCV : (uint32_t)y64;
-    Cbo = cb64 > pp.maxCV ? pp.maxCV : (uint32_t)cb64;
-    Cro = cr64 > pp.maxCV ? pp.maxCV : (uint32_t)cr64;
+    int32_t cb, cr;
+    if (mode == H2Y_MODE_YCBCR) {
+        double yd = ((pp.kr * (double)R + pp.kg * (double)G) + pp.kb * (double)B) + 0.5;
+        float tmpF = (float)yd;
+        Yo = f2u_clamped(tmpF, pp.maxCV);
+        if (EXACT_DIV) {
+            cb = sat_i32_f64((double)(B - tmpF) / pp.dcb + 0.5);
+            cr = sat_i32_f64((double)(R - tmpF) / pp.dcr + 0.5);
+        } else {
+            bool u1, u2;
+            cb = div_round_trunc_fast(B - tmpF, pp.inv_dcb, &u1);
+            cr = div_round_trunc_fast(R - tmpF, pp.inv_dcr, &u2);
+            *uncertain = u1 | u2;
+        }
+    } else if (mode == H2Y_MODE_YDZDX) {
+        Yo = f2u_clamped(G, pp.maxCV);
+        double hg = (double)(-G) * 0.5; /* -G/2.0: exact either way */
+        cb = sat_i32_f64((hg + (double)B * 0.5) + 0.5);
+        cr = sat_i32_f64((hg + (double)R * 0.5) + 0.5);
+    } else {
+        Yo = f2u_clamped(G, pp.maxCV);
+        cb = sat_i32_f64((double)(pp.P * G + pp.Q * B) + 0.5);
+        cr = sat_i32_f64((double)(pp.RR * R + pp.S * G) + 0.5);
+    }
+    Cbo = chroma_clamped(cb, pp.half_m1, pp.maxCV);
+    Cro = chroma_clamped(cr, pp.half_m1, pp.maxCV);
 }
 
-/* scale step, convert.cpp:1123-1145: separate multiply and add in binary32 */
-H2Y_FN float pix_scale(float v, float mul, float add, int scale_mode)
+/* scale step, convert.cpp:1123-1145: separate multiply and add in binary32.
+ * Full range has no add in the reference; add is then 0.0f, which leaves every
+ * product unchanged (-0.0 + 0.0 = +0.0 converts to the same integer). */
+H2Y_FN float pix_scale(float v, float mul, float add)
 {
     float r = v * mul;
-    if (scale_mode != H2Y_SCALE_FULL) r = r + add;
-    return r;
+    return r + add;
 }
 
-/* write_yuv per-sample step, tiff.cpp:469-478 (luma) / 502-511,533-543 (chroma) */
+/* write_yuv per-sample step, tiff.cpp:469-478 (luma) / 502-511,533-543 (chroma).
+ * lo/hi are minVR/maxVR (minVRC/maxVRC for chroma), or 0/maxCV when the output
+ * is full range -- set up once in pix_params. */
 H2Y_FN uint32_t pix_yuv_clamp(const pix_params &pp, uint32_t v, bool chroma)
 {
-    v = (v >> pp.down_shift) & 0xFFFFu;
-    if (pp.full_range == 0) {
-        uint32_t lo = chroma ? pp.clo : pp.ylo, hi = chroma ? pp.chi : pp.yhi;
-        v = v < lo ? lo : v;
-        v = v > hi ? hi : v;
-    } else {
-        v = v > pp.out_maxCV ? pp.out_maxCV : v;
-    }
+    v = v >> pp.down_shift;
+    const uint32_t lo = chroma ? pp.clo : pp.ylo, hi = chroma ? pp.chi : pp.yhi;
+    v = v < lo ? lo : v;
+    v = v > hi ? hi : v;
     return v;
 }
 

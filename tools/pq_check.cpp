@@ -65,8 +65,8 @@ int main(int argc, char **argv)
     bool slow_only = !strcmp(argv[1], "slow");
     uint32_t lo = (uint32_t)strtoul(argv[2], 0, 0), hi = (uint32_t)strtoul(argv[3], 0, 0);
     int T = argc > 4 ? atoi(argv[4]) : 8;
-    std::vector<pq_recA> A(H2Y_PQ_NSEG);
-    std::vector<pq_recB> B(H2Y_PQ_NSEG);
+    std::vector<pq_recA> A(H2Y_PQ_NREC);
+    std::vector<pq_recB> B(H2Y_PQ_NREC);
     pq_build_table(A.data(), B.data());
     std::atomic<uint64_t> mism{0}, nslow{0}, maxerr{0}, total{0};
     std::vector<std::thread> th;
@@ -91,14 +91,8 @@ int main(int argc, char **argv)
                         ns++;
                     } else {
                         /* fast-tier error in double ulps: recompute v */
-                        uint32_t bits = (uint32_t)u;
-                        uint32_t idx = (bits - (H2Y_PQ_SEG_BASE << H2Y_PQ_LOW_BITS)) >> H2Y_PQ_LOW_BITS;
-                        float f = bits2f((bits & ((1u << H2Y_PQ_LOW_BITS) - 1u)) | 0x3F800000u);
-                        float uu = __builtin_fmaf(f, 128.0f, -129.0f);
-                        float p = __builtin_fmaf(B[idx].c4, uu, B[idx].c3);
-                        double ud = uu, v = __builtin_fma((double)p, ud, B[idx].c2);
-                        v = __builtin_fma(v, ud, A[idx].c1);
-                        v = __builtin_fma(v, ud, A[idx].c0);
+                        uint32_t off = pq_rec_offset((uint32_t)u) / 16;
+                        double v = pq_poly((uint32_t)u, A[off], B[off]);
                         int64_t d = (int64_t)(d2bits(v) - d2bits(vref));
                         uint64_t ad = d < 0 ? -d : d;
                         if (ad > me) me = ad;

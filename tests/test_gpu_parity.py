@@ -259,3 +259,26 @@ def test_descriptor_errors(ctx):
     with pytest.raises(h.H2YError) as e:
         ctx.convert_frame(d, [np.zeros(66 * 32, np.float32)] * 3)
     assert e.value.code == 1
+
+
+def test_cli_writes_reference_bytes(tmp_path):
+    """The C++ host program with the reference's flags: 64x32 synthetic frame, 10-bit
+    BT.2020nc 4:2:0 FIR -> the md5 SURVEY 8c recorded from the reference binary; a second
+    invocation appends (tiff.cpp:440)."""
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "hdr2yuv_amd", "hdr2yuv")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(root, "hdr2yuv_amd", "cli"), "--no-print-directory"], check=True)
+    out = str(tmp_path / "o.yuv")
+    cmd = [exe, "--synthetic", "0", "--src_pic_width", "64", "--src_pic_height", "32", "--dst_filename", out,
+           "--dst_bit_depth", "10", "--src_transfer_characteristics", "8", "--dst_transfer_characteristics", "16",
+           "--dst_matrix_coeffs", "9", "--dst_colour_primaries", "9", "--dst_chroma_format_idc", "1",
+           "--dst_video_full_range_flag", "0", "--chroma_resampler_type", "1"]
+    for n in (1, 2):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        data = open(out, "rb").read()
+        assert len(data) == 6144 * n
+        assert hashlib.md5(data[-6144:]).hexdigest() == KNOWN["cases"]["tiny_64x32_2020_10b_fir"]["md5"]

@@ -1,0 +1,63 @@
+"""Host build of the device arithmetic (hdr2yuv_amd/csrc/h2y_math.h) against the
+reference formula with this machine's libm, through tools/pq_check.cpp.
+Sampled here; the exhaustive runs (every non-negative float) are in DESIGN.md."""
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "build", "pq_check")
+
+
+@pytest.fixture(scope="module")
+def pq_check():
+    os.makedirs(os.path.dirname(EXE), exist_ok=True)
+    src = os.path.join(ROOT, "tools", "pq_check.cpp")
+    hdr = os.path.join(ROOT, "hdr2yuv_amd", "csrc", "h2y_math.h")
+    if not os.path.exists(EXE) or os.path.getmtime(EXE) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.run(["g++", "-O2", "-ffp-contract=off", "-mfma", "-std=c++17", "-pthread", src, "-o", EXE], check=True)
+    return EXE
+
+
+def _run(exe, *args):
+    r = subprocess.run([exe, *args], capture_output=True, text=True)
+    return r.returncode, r.stdout + r.stderr
+
+
+def test_fast_tier_whole_top_binades(pq_check):
+    # every float in [0.25, 2): 3 binades, 25M values
+    rc, out = _run(pq_check, "range", "0x3e800000", "0x40000000", "4")
+    assert rc == 0, out
+    m = re.search(r"mismatches (\d+), slow tier (\d+) .* max fast err (\d+)", out)
+    assert int(m.group(1)) == 0
+    assert int(m.group(3)) < 1024  # well inside the 4096-ulp ambiguity window
+    assert int(m.group(2)) < 25165824 // 20000
+
+
+def test_fast_tier_sampled_low_binades(pq_check):
+    for lo in (0x33800000, 0x36000000, 0x39000000, 0x3C000000):
+        rc, out = _run(pq_check, "range", hex(lo), hex(lo + 0x100000), "4")
+        assert rc == 0, out
+
+
+def test_out_of_table_goes_to_slow_tier(pq_check):
+    for lo, hi in ((0x00000000, 0x00002000), (0x33000000, 0x33002000), (0x40000000, 0x40002000), (0x7F7FF000, 0x7F800001)):
+        rc, out = _run(pq_check, "range", hex(lo), hex(hi), "2")
+        assert rc == 0, out
+        m = re.search(r": (\d+) floats, mismatches 0, slow tier (\d+)", out)
+        assert m and m.group(1) == m.group(2)
+
+
+def test_slow_tier_sampled(pq_check):
+    rc, out = _run(pq_check, "slow", "0x3f000000", "0x3f040000", "4")
+    assert rc == 0, out
+
+
+def test_pow_dd_within_one_ulp_of_libm(pq_check):
+    rc, out = _run(pq_check, "pow", "300000")
+    assert rc == 0
+    m = re.search(r"m1 differ (\d+) / (\d+) .* m2 differ (\d+) .* >1ulp: (\d+)", out)
+    assert int(m.group(4)) == 0
+    assert int(m.group(1)) < 0.005 * int(m.group(2)) and int(m.group(3)) < 0.005 * int(m.group(2))

@@ -10,6 +10,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -71,6 +72,7 @@ struct h2y_ctx {
     assumed_stats *d_assumed = nullptr, *h_assumed = nullptr; /* [2]: [0] batch, [1] redo */
     uint16_t *d_tmp = nullptr;
     size_t tmp_cap = 0;
+
     /* staging for the host-buffer entry */
     void *d_in = nullptr;
     size_t in_cap = 0;
@@ -199,7 +201,7 @@ struct geom {
     bool narrow;
     uint32_t wq, wq_magic, tiles, chunks;
 };
-geom make_geom(const h2y_desc *d)
+geom make_geom(const h2y_desc *d, int threads)
 {
     geom g;
     g.narrow = (d->width % 4) != 0;
@@ -207,17 +209,35 @@ geom make_geom(const h2y_desc *d)
     g.wq_magic = (uint32_t)(0x100000000ull / g.wq);
     if (g.wq == 1) g.wq_magic = 0xFFFFFFFFu;
     g.tiles = g.wq * (uint32_t)((d->height + 1) / 2);
-    g.chunks = (g.tiles + H2Y_FUSED_THREADS - 1) / H2Y_FUSED_THREADS;
+    g.chunks = (g.tiles + threads - 1) / threads;
     return g;
 }
 
-int grid_for(const h2y_ctx *ctx, const h2y_desc *d, int out_kind, int mode, bool narrow, uint64_t total_chunks)
+int grid_for(const h2y_ctx *ctx, const fused_variant &v, uint64_t total_chunks)
 {
     /* persistent grid: exactly the blocks the chip holds at once */
-    uint64_t g = (uint64_t)ctx->n_cu * h2y_fused_blocks_per_cu(in_kind_of(d), out_kind, mode, narrow);
+    uint64_t g = (uint64_t)ctx->n_cu * h2y_fused_blocks_per_cu(v);
     if (g > total_chunks) g = total_chunks;
     if (g < 1) g = 1;
     return (int)g;
+}
+
+/* known: the floor/ceiling the kernels will assume, when the HOST knows them (hint or
+ * override); NULL when they only exist in device memory (stats pre-pass). */
+fused_variant pick_variant(const h2y_desc *d, const pix_params &pp, int out_kind, const assumed_stats *known)
+{
+    fused_variant v;
+    v.in_kind = in_kind_of(d);
+    v.out_kind = out_kind;
+    v.mode = pp.mode;
+    v.narrow = (d->width % 4) != 0;
+    v.pipe = 0;
+    if (pp.convert_transfer && !v.narrow) {
+        bool ident = known != nullptr;
+        for (int c = 0; c < 3 && ident; c++) ident = known->floor_[c] == 0 && known->ceil_[c] == 1;
+        v.pipe = ident ? 1 : 2; /* 2 is always valid: (x - 0) / 1 == x exactly */
+    }
+    return v;
 }
 
 int out_kind_of(const h2y_desc *d)
@@ -228,12 +248,13 @@ int out_kind_of(const h2y_desc *d)
 
 /* launch fused (+FIR) over frames [0,n) whose frame_io entries are in h_frames */
 int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, const assumed_stats *d_assumed,
-               bool check, int fstats_offset, bool time_it)
+               const assumed_stats *known, bool check, int fstats_offset, bool time_it)
 {
     pix_params pp;
     derive_params(d, &pp, false);
-    const geom g = make_geom(d);
     const int out_kind = out_kind_of(d);
+    const fused_variant var = pick_variant(d, pp, out_kind, known);
+    const geom g = make_geom(d, H2Y_FUSED_THREADS);
     const size_t npix = (size_t)d->width * d->height;
     const int step = out_kind == H2Y_OUT_444TMP ? kFirSubBatch : n;
     if (out_kind == H2Y_OUT_444TMP) {
@@ -253,7 +274,7 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         }
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frames + f0, ctx->h_frames + f0, nf * sizeof(frame_io), hipMemcpyHostToDevice,
                                     ctx->stream));
-        const int grid = grid_for(ctx, d, out_kind, pp.mode, g.narrow, (uint64_t)g.chunks * nf);
+        const int grid = grid_for(ctx, var, (uint64_t)g.chunks * nf);
         int rc = ensure(ctx, ctx->d_partial, ctx->partial_cap, (size_t)nf * grid * 6 * sizeof(float));
         if (rc) return rc;
         fused_args a;
@@ -271,7 +292,7 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         a.pp = pp;
         const bool ev = time_it && ctx->n_ev < kMaxEvents;
         if (ev) HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->n_ev][0], ctx->stream));
-        HIP_TRY(ctx, h2y_launch_fused(in_kind_of(d), out_kind, pp.mode, g.narrow, grid, ctx->stream, a));
+        HIP_TRY(ctx, h2y_launch_fused(var, grid, ctx->stream, a));
         if (ev) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->n_ev][1], ctx->stream));
             ctx->n_ev++;
@@ -447,10 +468,11 @@ int h2y_ctx_create(int device, h2y_ctx **out)
         std::vector<pq_recA> A(H2Y_PQ_NREC);
         std::vector<pq_recB> B(H2Y_PQ_NREC);
         pq_build_table(A.data(), B.data());
-        HIP_TRY(ctx, hipMalloc(&ctx->d_table, H2Y_PQ_TABLE_BYTES));
-        HIP_TRY(ctx, hipMemcpy(ctx->d_table, A.data(), H2Y_PQ_NREC * sizeof(pq_recA), hipMemcpyHostToDevice));
-        HIP_TRY(ctx, hipMemcpy((char *)ctx->d_table + H2Y_PQ_NREC * sizeof(pq_recA), B.data(), H2Y_PQ_NREC * sizeof(pq_recB),
-                               hipMemcpyHostToDevice));
+        char *t = nullptr;
+        HIP_TRY(ctx, hipMalloc((void **)&t, H2Y_PQ_TABLE_BYTES));
+        ctx->d_table = t;
+        HIP_TRY(ctx, hipMemcpy(t, A.data(), H2Y_PQ_NREC * 16, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(t + H2Y_PQ_NREC * 16, B.data(), H2Y_PQ_NREC * 16, hipMemcpyHostToDevice));
     }
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_assumed, 2 * sizeof(assumed_stats)));
     HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_assumed, 2 * sizeof(assumed_stats), hipHostMallocDefault));
@@ -518,6 +540,7 @@ int h2y_convert_batch_enqueue(h2y_ctx *ctx, const h2y_desc *d, int n_frames, con
     ctx->n_ev = 0;
     const bool needs_stats = d->src_transfer != d->dst_transfer; /* convert.cpp:930-940: stats are only read then */
     bool check = false;
+    bool host_knows = true;
     assumed_stats *as = ctx->h_assumed;
     if (!needs_stats || d->stats_override) {
         for (int c = 0; c < 3; c++) {
@@ -538,8 +561,9 @@ int h2y_convert_batch_enqueue(h2y_ctx *ctx, const h2y_desc *d, int n_frames, con
         rc = run_stats(ctx, d, ctx->p_frames[0].in, (int)ctx->frames_cap, ctx->d_assumed);
         if (rc) return rc;
         check = true;
+        host_knows = false; /* the values exist only in device memory */
     }
-    rc = run_frames(ctx, d, ctx->p_frames.data(), n_frames, ctx->d_assumed, check, 0, true);
+    rc = run_frames(ctx, d, ctx->p_frames.data(), n_frames, ctx->d_assumed, host_knows ? ctx->h_assumed : nullptr, check, 0, true);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_fstats, ctx->d_fstats, n_frames * sizeof(frame_stats), hipMemcpyDeviceToHost, ctx->stream));
     ctx->pending = true;
@@ -578,7 +602,7 @@ int h2y_batch_finish(h2y_ctx *ctx, int *n_redone)
                 as->ceil_[c] = ctx->h_fstats[f].ceil_[c];
             }
             HIP_TRY(ctx, hipMemcpyAsync(ctx->d_assumed + 1, as, sizeof *as, hipMemcpyHostToDevice, ctx->stream));
-            int rc = run_frames(ctx, d, &ctx->p_frames[f], 1, ctx->d_assumed + 1, false, (int)ctx->frames_cap, false);
+            int rc = run_frames(ctx, d, &ctx->p_frames[f], 1, ctx->d_assumed + 1, as, false, (int)ctx->frames_cap, false);
             if (rc) return rc;
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             redone++;
@@ -627,9 +651,11 @@ int h2y_convert_frame(h2y_ctx *ctx, const h2y_desc *d, const void *const in_plan
     io.tmp_cb = io.tmp_cr = nullptr;
     /* the reference's order: pic_stats first, then the pixel loops with its result */
     const bool needs_stats = d->src_transfer != d->dst_transfer;
+    bool host_knows = true;
     if (needs_stats && !d->stats_override) {
         rc = run_stats(ctx, d, io.in, (int)ctx->frames_cap, ctx->d_assumed);
         if (rc) return rc;
+        host_knows = false;
     } else {
         assumed_stats *as = ctx->h_assumed;
         for (int c = 0; c < 3; c++) {
@@ -639,7 +665,7 @@ int h2y_convert_frame(h2y_ctx *ctx, const h2y_desc *d, const void *const in_plan
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_assumed, as, sizeof *as, hipMemcpyHostToDevice, ctx->stream));
     }
     ctx->n_ev = 0;
-    rc = run_frames(ctx, d, &io, 1, ctx->d_assumed, false, 0, true);
+    rc = run_frames(ctx, d, &io, 1, ctx->d_assumed, host_knows ? ctx->h_assumed : nullptr, false, 0, true);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(out_yuv, ctx->d_out, ob, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -694,7 +720,13 @@ int h2y_matrix_convert(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_assumed, as, sizeof *as, hipMemcpyHostToDevice, ctx->stream));
     pix_params pp;
     derive_params(d, &pp, true);
-    const geom g = make_geom(d);
+    fused_variant var;
+    var.in_kind = in_kind_of(d);
+    var.out_kind = H2Y_OUT_444TMP;
+    var.mode = pp.mode;
+    var.narrow = (d->width % 4) != 0;
+    var.pipe = (pp.convert_transfer && !var.narrow) ? 2 : 0;
+    const geom g = make_geom(d, H2Y_FUSED_THREADS);
     frame_io io;
     for (int c = 0; c < 3; c++) io.in[c] = d_in[c];
     io.out = d_out444[0];
@@ -702,7 +734,7 @@ int h2y_matrix_convert(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3
     io.tmp_cr = d_out444[2];
     ctx->h_frames[0] = io;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frames, ctx->h_frames, sizeof(frame_io), hipMemcpyHostToDevice, ctx->stream));
-    const int grid = grid_for(ctx, d, H2Y_OUT_444TMP, pp.mode, g.narrow, g.chunks);
+    const int grid = grid_for(ctx, var, g.chunks);
     rc = ensure(ctx, ctx->d_partial, ctx->partial_cap, (size_t)grid * 6 * sizeof(float));
     if (rc) return rc;
     fused_args a;
@@ -718,7 +750,7 @@ int h2y_matrix_convert(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3
     a.partial = ctx->d_partial;
     a.assumed = ctx->d_assumed;
     a.pp = pp;
-    HIP_TRY(ctx, h2y_launch_fused(in_kind_of(d), H2Y_OUT_444TMP, pp.mode, g.narrow, grid, ctx->stream, a));
+    HIP_TRY(ctx, h2y_launch_fused(var, grid, ctx->stream, a));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return H2Y_OK;
 }

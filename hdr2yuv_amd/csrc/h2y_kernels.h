@@ -57,6 +57,13 @@ struct fused_args {
     h2y::pix_params pp;       /* offset/range/norm_identity are filled in-kernel from *assumed */
 };
 
+/* which instantiation of the fused kernel */
+struct fused_variant {
+    int in_kind, out_kind, mode;
+    int pipe;      /* 0 runtime flags, 1 LINEAR->PQ with floor 0/ceiling 1, 2 LINEAR->PQ general normalisation */
+    bool narrow;   /* width % 4 != 0: scalar-load variant */
+};
+
 struct stats_args {
     const void *in[3];
     size_t npix;
@@ -83,8 +90,8 @@ struct fir_args {
     h2y::pix_params pp;
 };
 
-int h2y_fused_blocks_per_cu(int in_kind, int out_kind, int mode, bool narrow);
-hipError_t h2y_launch_fused(int in_kind, int out_kind, int mode, bool narrow, int grid, hipStream_t st, const fused_args &a);
+int h2y_fused_blocks_per_cu(const fused_variant &v);
+hipError_t h2y_launch_fused(const fused_variant &v, int grid, hipStream_t st, const fused_args &a);
 hipError_t h2y_launch_stats(int in_kind, int grid, hipStream_t st, const stats_args &a);
 hipError_t h2y_launch_stats_final(int n_frames, hipStream_t st, const final_args &a);
 hipError_t h2y_launch_fir420(hipStream_t st, const fir_args &a);

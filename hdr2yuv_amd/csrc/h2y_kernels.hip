@@ -165,19 +165,29 @@ __device__ __attribute__((noinline)) ycc pixel_careful(const pix_params *spp /* 
     return o;
 }
 
-template <int MODE>
-__device__ __forceinline__ void pixel(const pix_params &pp, const pix_params *spp, const pq_recA *sA, const pq_recB *sB,
-                                      float G, float B, float R, uint32_t &Y, uint32_t &Cb, uint32_t &Cr)
+/* PIPE: what is known at compile time about the front of the pixel pipeline */
+#define H2Y_PIPE_RUNTIME 0  /* read pp.convert_transfer / pp.norm_identity */
+#define H2Y_PIPE_PQ_IDENT 1 /* LINEAR -> PQ, floor 0 / ceiling 1: no normalisation arithmetic */
+#define H2Y_PIPE_PQ_NORM 2  /* LINEAR -> PQ with (x - offset) / range */
+
+/* normalisation of one sample, convert.cpp:1017-1019: binary32 subtract, IEEE divide */
+template <int PIPE> __device__ __forceinline__ float norm1(const pix_params &pp, int c, float v)
 {
-    if (pp.convert_transfer && !pp.norm_identity) {
-        /* convert.cpp:1017-1019, binary32 subtract and IEEE divide */
-        G = (G - pp.offset[0]) / pp.range[0];
-        B = (B - pp.offset[1]) / pp.range[1];
-        R = (R - pp.offset[2]) / pp.range[2];
-    }
+    const bool conv = PIPE == H2Y_PIPE_RUNTIME ? pp.convert_transfer : true;
+    const bool ident = PIPE == H2Y_PIPE_RUNTIME ? pp.norm_identity : PIPE == H2Y_PIPE_PQ_IDENT;
+    return (conv && !ident) ? (v - pp.offset[c]) / pp.range[c] : v;
+}
+
+/* fast tier of one pixel (inputs normalised).  Returns true when the result
+ * cannot be trusted and pixel_careful() must be used instead. */
+template <int MODE, int PIPE>
+__device__ __forceinline__ bool pixel_fast(const pix_params &pp, const pq_recA *sA, const pq_recB *sB, float G, float B, float R,
+                                           uint32_t &Y, uint32_t &Cb, uint32_t &Cr)
+{
+    const bool conv = PIPE == H2Y_PIPE_RUNTIME ? pp.convert_transfer : true;
     float g = G, b = B, r = R;
     bool unsure = false;
-    if (pp.convert_transfer) {
+    if (conv) {
         bool sg, sb, sr;
         g = pix_scale(pq_fast(G, sA, sB, &sg), pp.mulY, pp.addY);
         b = pix_scale(pq_fast(B, sA, sB, &sb), pp.mulC, pp.addC);
@@ -186,7 +196,18 @@ __device__ __forceinline__ void pixel(const pix_params &pp, const pix_params *sp
     }
     bool um;
     pix_matrix<MODE, false>(pp, g, b, r, Y, Cb, Cr, &um);
-    if (__builtin_expect(unsure | um, 0)) {
+    return unsure | um;
+}
+
+/* one pixel, both tiers (used by the narrow-width kernel) */
+template <int MODE>
+__device__ __forceinline__ void pixel(const pix_params &pp, const pix_params *spp, const pq_recA *sA, const pq_recB *sB,
+                                      float G, float B, float R, uint32_t &Y, uint32_t &Cb, uint32_t &Cr)
+{
+    G = norm1<H2Y_PIPE_RUNTIME>(pp, 0, G);
+    B = norm1<H2Y_PIPE_RUNTIME>(pp, 1, B);
+    R = norm1<H2Y_PIPE_RUNTIME>(pp, 2, R);
+    if (__builtin_expect(pixel_fast<MODE, H2Y_PIPE_RUNTIME>(pp, sA, sB, G, B, R, Y, Cb, Cr), 0)) {
         const ycc o = pixel_careful<MODE>(spp, G, B, R);
         Y = o.y;
         Cb = o.cb;
@@ -223,23 +244,136 @@ __device__ __forceinline__ uint32_t udiv_magic(uint32_t n, uint32_t d, uint32_t 
     return q;
 }
 
-__device__ __forceinline__ void stage_table(const void *table, pq_recA *s_tab)
+template <int THREADS> __device__ __forceinline__ void stage_table(const void *table, pq_recA *s_tab)
 {
     const uint4 *g = reinterpret_cast<const uint4 *>(table);
     uint4 *l = reinterpret_cast<uint4 *>(s_tab);
-    for (int i = threadIdx.x; i < 2 * H2Y_PQ_NREC; i += H2Y_FUSED_THREADS) l[i] = g[i];
+    for (int i = threadIdx.x; i < 2 * H2Y_PQ_NREC; i += THREADS) l[i] = g[i];
+}
+
+/* ---- the thread tile: 4 columns x 2 rows ------------------------------- */
+struct tile_pos {
+    uint32_t rp, x; /* row pair, first column */
+    size_t i0, i1;  /* sample index of row 0 / row 1 (row 1 == row 0 when the picture ends) */
+    bool row1;
+};
+__device__ __forceinline__ tile_pos tile_locate(uint32_t tt, uint32_t W, uint32_t H, uint32_t WQ, uint32_t magic)
+{
+    tile_pos t;
+    uint32_t cg;
+    t.rp = udiv_magic(tt, WQ, magic, cg);
+    t.x = cg * 4;
+    const uint32_t y = t.rp * 2;
+    t.row1 = (y + 1) < H;
+    t.i0 = (size_t)y * W + t.x;
+    t.i1 = t.row1 ? t.i0 + W : t.i0;
+    return t;
+}
+struct tile_in {
+    float g0[4], b0[4], r0[4], g1[4], b1[4], r1[4];
+};
+template <int IN_KIND> __device__ __forceinline__ void tile_load(const frame_io &io, const tile_pos &t, tile_in &v)
+{
+    typedef in_traits<IN_KIND> IN;
+    IN::load4(io.in[0], t.i0, v.g0);
+    IN::load4(io.in[1], t.i0, v.b0);
+    IN::load4(io.in[2], t.i0, v.r0);
+    IN::load4(io.in[0], t.i1, v.g1);
+    IN::load4(io.in[1], t.i1, v.b1);
+    IN::load4(io.in[2], t.i1, v.r1);
+}
+/* packed results of a tile, ready to store */
+struct tile_out {
+    uint32_t yp0[2], yp1[2];                     /* Y rows, two u16 per dword */
+    uint32_t cbp0[2], cbp1[2], crp0[2], crp1[2]; /* 4:4:4 chroma rows */
+    uint32_t cb_box, cr_box;                     /* 4:2:0 box chroma, two samples each */
+};
+template <int OUT_KIND>
+__device__ __forceinline__ void tile_pack(const pix_params &pp, int jb, const uint32_t (&Y)[4], uint32_t (&Cb)[4],
+                                          uint32_t (&Cr)[4], tile_out &o)
+{
+    o.yp0[jb] = pix_yuv_clamp(pp, Y[0], false) | (pix_yuv_clamp(pp, Y[1], false) << 16);
+    o.yp1[jb] = pix_yuv_clamp(pp, Y[2], false) | (pix_yuv_clamp(pp, Y[3], false) << 16);
+    if (OUT_KIND == H2Y_OUT_420BOX) {
+        /* convert.cpp:157-160: (a+b+c+d)/4, unsigned truncation; then write_yuv's clamp */
+        uint32_t cb = pix_yuv_clamp(pp, (Cb[0] + Cb[1] + Cb[2] + Cb[3]) >> 2, true);
+        uint32_t cr = pix_yuv_clamp(pp, (Cr[0] + Cr[1] + Cr[2] + Cr[3]) >> 2, true);
+        if (jb == 0) { o.cb_box = cb; o.cr_box = cr; }
+        else { o.cb_box |= cb << 16; o.cr_box |= cr << 16; }
+    } else {
+        if (OUT_KIND == H2Y_OUT_444) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                Cb[q] = pix_yuv_clamp(pp, Cb[q], true);
+                Cr[q] = pix_yuv_clamp(pp, Cr[q], true);
+            }
+        }
+        o.cbp0[jb] = Cb[0] | (Cb[1] << 16); o.cbp1[jb] = Cb[2] | (Cb[3] << 16);
+        o.crp0[jb] = Cr[0] | (Cr[1] << 16); o.crp1[jb] = Cr[2] | (Cr[3] << 16);
+    }
+}
+template <int OUT_KIND>
+__device__ __forceinline__ void tile_store(const frame_io &io, const tile_pos &t, uint32_t W, uint32_t H, const tile_out &o)
+{
+    const size_t npix = (size_t)W * H;
+    uint16_t *Yp = io.out;
+    *reinterpret_cast<uint2 *>(Yp + t.i0) = make_uint2(o.yp0[0], o.yp0[1]);
+    if (t.row1) *reinterpret_cast<uint2 *>(Yp + t.i1) = make_uint2(o.yp1[0], o.yp1[1]);
+    if (OUT_KIND == H2Y_OUT_420BOX) {
+        const uint32_t wc = W >> 1;
+        const size_t ic = (size_t)t.rp * wc + (t.x >> 1);
+        uint16_t *Cbp = io.out + npix, *Crp = Cbp + (size_t)wc * (H >> 1);
+        *reinterpret_cast<uint32_t *>(Cbp + ic) = o.cb_box;
+        *reinterpret_cast<uint32_t *>(Crp + ic) = o.cr_box;
+    } else {
+        uint16_t *Cbp = OUT_KIND == H2Y_OUT_444 ? io.out + npix : io.tmp_cb;
+        uint16_t *Crp = OUT_KIND == H2Y_OUT_444 ? io.out + 2 * npix : io.tmp_cr;
+        *reinterpret_cast<uint2 *>(Cbp + t.i0) = make_uint2(o.cbp0[0], o.cbp0[1]);
+        *reinterpret_cast<uint2 *>(Crp + t.i0) = make_uint2(o.crp0[0], o.crp0[1]);
+        if (t.row1) {
+            *reinterpret_cast<uint2 *>(Cbp + t.i1) = make_uint2(o.cbp1[0], o.cbp1[1]);
+            *reinterpret_cast<uint2 *>(Crp + t.i1) = make_uint2(o.crp1[0], o.crp1[1]);
+        }
+    }
+}
+
+/* exact tier for one tile: pixel by pixel, each with its own (rarely taken)
+ * branch to the careful tier.  (A single straight-line block for all eight
+ * pixels with one branch at the end was tried: the register allocator then
+ * spills and the kernel is slower.) */
+template <int OUT_KIND, int MODE, int PIPE>
+__device__ __forceinline__ void tile_exact(const pix_params &pp, const pix_params *spp, const pq_recA *sA, const pq_recB *sB,
+                                           tile_in &v, tile_out &o)
+{
+#pragma unroll
+    for (int jb = 0; jb < 2; jb++) {
+        uint32_t Y[4], Cb[4], Cr[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int col = 2 * jb + (q & 1);
+            const float G = norm1<PIPE>(pp, 0, q < 2 ? v.g0[col] : v.g1[col]);
+            const float B = norm1<PIPE>(pp, 1, q < 2 ? v.b0[col] : v.b1[col]);
+            const float R = norm1<PIPE>(pp, 2, q < 2 ? v.r0[col] : v.r1[col]);
+            if (__builtin_expect(pixel_fast<MODE, PIPE>(pp, sA, sB, G, B, R, Y[q], Cb[q], Cr[q]), 0)) {
+                const ycc c = pixel_careful<MODE>(spp, G, B, R);
+                Y[q] = c.y;
+                Cb[q] = c.cb;
+                Cr[q] = c.cr;
+            }
+        }
+        tile_pack<OUT_KIND>(pp, jb, Y, Cb, Cr, o);
+    }
 }
 
 /*
- * k_fused: one thread = 4 columns x 2 rows of one frame.
+ * k_fused: one thread = 4 columns x 2 rows of one frame, exact tier only.
  *
- * A chunk is H2Y_FUSED_THREADS consecutive thread-tiles of ONE frame (chunks
- * never straddle frames); global chunk g belongs to block g % gridDim.x, so a
- * block walks the frames in order and all its threads are always in the same
- * frame.  After its last chunk of a frame the block reduces the min/max its
- * threads saw and stores six floats to partial[frame][block] -- every
- * (frame, block) slot is written exactly once per launch, no atomics, no
- * initialisation.
+ * A chunk is blockDim.x consecutive thread-tiles of ONE frame (chunks never
+ * straddle frames); global chunk g belongs to block g % gridDim.x, so a block
+ * walks the frames in order and all its threads are always in the same frame.
+ * After its last chunk of a frame the block reduces the min/max its threads
+ * saw and stores six floats to partial[frame][block] -- every (frame, block)
+ * slot is written exactly once per launch, no atomics, no initialisation.
  *
  * OUT_KIND:
  *   H2Y_OUT_420BOX  Y final; Cb/Cr = truncating mean of the thread's own two
@@ -249,25 +383,20 @@ __device__ __forceinline__ void stage_table(const void *table, pq_recA *s_tab)
  *                   range-clamped) into scratch planes for k_fir420
  * MODE: H2Y_MODE_YCBCR / H2Y_MODE_YDZDX compiled in, or H2Y_MODE_RUNTIME.
  */
-template <int IN_KIND, int OUT_KIND, int MODE>
+template <int IN_KIND, int OUT_KIND, int MODE, int PIPE>
 __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused(fused_args a)
 {
     __shared__ pq_recA s_tab[2 * H2Y_PQ_NREC]; /* A records, then B records */
     const pq_recA *sA = s_tab;
     const pq_recB *sB = reinterpret_cast<const pq_recB *>(s_tab + H2Y_PQ_NREC);
     __shared__ float s_red[(H2Y_FUSED_THREADS / WAVE) * 6];
-
     __shared__ pix_params s_pp;
-    if (a.pp.convert_transfer) stage_table(a.table, s_tab);
-    typedef in_traits<IN_KIND> IN;
+    if (PIPE != H2Y_PIPE_RUNTIME || a.pp.convert_transfer) stage_table<H2Y_FUSED_THREADS>(a.table, s_tab);
     const pix_params pp = with_assumed(a.pp, a.assumed);
     if (threadIdx.x == 0) s_pp = pp;
     __syncthreads();
 
-    const uint32_t W = a.width, H = a.height, WQ = a.wq;
-    const size_t npix = (size_t)W * H;
-    const uint32_t G = gridDim.x;
-
+    const uint32_t W = a.width, H = a.height, G = gridDim.x;
     for (int f = 0; f < a.n_frames; f++) {
         const frame_io io = a.frames[f];
         mm6 mm;
@@ -278,76 +407,18 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
         for (; k < a.chunks_per_frame; k += G) {
             const uint32_t tt = k * H2Y_FUSED_THREADS + threadIdx.x;
             if (tt >= a.tiles_per_frame) continue;
-            uint32_t cg;
-            const uint32_t rp = udiv_magic(tt, WQ, a.wq_magic, cg);
-            const uint32_t x = cg * 4, y = rp * 2;
-            const bool row1 = (y + 1) < H;
-            const size_t i0 = (size_t)y * W + x, i1 = row1 ? i0 + W : i0;
-
-            float g0[4], b0[4], r0[4], g1[4], b1[4], r1[4];
-            IN::load4(io.in[0], i0, g0);
-            IN::load4(io.in[1], i0, b0);
-            IN::load4(io.in[2], i0, r0);
-            IN::load4(io.in[0], i1, g1);
-            IN::load4(io.in[1], i1, b1);
-            IN::load4(io.in[2], i1, r1);
+            const tile_pos t = tile_locate(tt, W, H, a.wq, a.wq_magic);
+            tile_in v;
+            tile_load<IN_KIND>(io, t, v);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                mm.add2(0, g0[j], g1[j]);
-                mm.add2(1, b0[j], b1[j]);
-                mm.add2(2, r0[j], r1[j]);
+                mm.add2(0, v.g0[j], v.g1[j]);
+                mm.add2(1, v.b0[j], v.b1[j]);
+                mm.add2(2, v.r0[j], v.r1[j]);
             }
-
-            /* two 2x2 blocks, one after the other, results packed as soon as they exist */
-            uint32_t yp0[2], yp1[2], cbp0[2], cbp1[2], crp0[2], crp1[2];
-            uint32_t cb_box = 0, cr_box = 0;
-#pragma unroll
-            for (int jb = 0; jb < 2; jb++) {
-                uint32_t Y[4], Cb[4], Cr[4];
-                pixel<MODE>(pp, &s_pp, sA, sB, g0[2 * jb], b0[2 * jb], r0[2 * jb], Y[0], Cb[0], Cr[0]);
-                pixel<MODE>(pp, &s_pp, sA, sB, g0[2 * jb + 1], b0[2 * jb + 1], r0[2 * jb + 1], Y[1], Cb[1], Cr[1]);
-                pixel<MODE>(pp, &s_pp, sA, sB, g1[2 * jb], b1[2 * jb], r1[2 * jb], Y[2], Cb[2], Cr[2]);
-                pixel<MODE>(pp, &s_pp, sA, sB, g1[2 * jb + 1], b1[2 * jb + 1], r1[2 * jb + 1], Y[3], Cb[3], Cr[3]);
-                yp0[jb] = pix_yuv_clamp(pp, Y[0], false) | (pix_yuv_clamp(pp, Y[1], false) << 16);
-                yp1[jb] = pix_yuv_clamp(pp, Y[2], false) | (pix_yuv_clamp(pp, Y[3], false) << 16);
-                if (OUT_KIND == H2Y_OUT_420BOX) {
-                    /* convert.cpp:157-160: (a+b+c+d)/4, unsigned truncation; then write_yuv's clamp */
-                    uint32_t cb = pix_yuv_clamp(pp, (Cb[0] + Cb[1] + Cb[2] + Cb[3]) >> 2, true);
-                    uint32_t cr = pix_yuv_clamp(pp, (Cr[0] + Cr[1] + Cr[2] + Cr[3]) >> 2, true);
-                    cb_box |= cb << (16 * jb);
-                    cr_box |= cr << (16 * jb);
-                } else {
-                    if (OUT_KIND == H2Y_OUT_444) {
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            Cb[q] = pix_yuv_clamp(pp, Cb[q], true);
-                            Cr[q] = pix_yuv_clamp(pp, Cr[q], true);
-                        }
-                    }
-                    cbp0[jb] = Cb[0] | (Cb[1] << 16); cbp1[jb] = Cb[2] | (Cb[3] << 16);
-                    crp0[jb] = Cr[0] | (Cr[1] << 16); crp1[jb] = Cr[2] | (Cr[3] << 16);
-                }
-            }
-
-            uint16_t *Yp = io.out;
-            *reinterpret_cast<uint2 *>(Yp + i0) = make_uint2(yp0[0], yp0[1]);
-            if (row1) *reinterpret_cast<uint2 *>(Yp + i1) = make_uint2(yp1[0], yp1[1]);
-            if (OUT_KIND == H2Y_OUT_420BOX) {
-                const uint32_t wc = W >> 1;
-                const size_t ic = (size_t)rp * wc + (x >> 1);
-                uint16_t *Cbp = io.out + npix, *Crp = Cbp + (size_t)wc * (H >> 1);
-                *reinterpret_cast<uint32_t *>(Cbp + ic) = cb_box;
-                *reinterpret_cast<uint32_t *>(Crp + ic) = cr_box;
-            } else {
-                uint16_t *Cbp = OUT_KIND == H2Y_OUT_444 ? io.out + npix : io.tmp_cb;
-                uint16_t *Crp = OUT_KIND == H2Y_OUT_444 ? io.out + 2 * npix : io.tmp_cr;
-                *reinterpret_cast<uint2 *>(Cbp + i0) = make_uint2(cbp0[0], cbp0[1]);
-                *reinterpret_cast<uint2 *>(Crp + i0) = make_uint2(crp0[0], crp0[1]);
-                if (row1) {
-                    *reinterpret_cast<uint2 *>(Cbp + i1) = make_uint2(cbp1[0], cbp1[1]);
-                    *reinterpret_cast<uint2 *>(Crp + i1) = make_uint2(crp1[0], crp1[1]);
-                }
-            }
+            tile_out o;
+            tile_exact<OUT_KIND, MODE, PIPE>(pp, &s_pp, sA, sB, v, o);
+            tile_store<OUT_KIND>(io, t, W, H, o);
         }
         block_store_mm<H2Y_FUSED_THREADS / WAVE>(mm, s_red, a.partial + ((size_t)f * G + blockIdx.x) * 6);
     }
@@ -366,7 +437,7 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS) void k_fused_narrow(fused_args a
     const pq_recB *sB = reinterpret_cast<const pq_recB *>(s_tab + H2Y_PQ_NREC);
     __shared__ float s_red[(H2Y_FUSED_THREADS / WAVE) * 6];
     __shared__ pix_params s_pp;
-    if (a.pp.convert_transfer) stage_table(a.table, s_tab);
+    if (a.pp.convert_transfer) stage_table<H2Y_FUSED_THREADS>(a.table, s_tab);
     typedef in_traits<IN_KIND> IN;
     const pix_params pp = with_assumed(a.pp, a.assumed);
     if (threadIdx.x == 0) s_pp = pp;
@@ -559,45 +630,53 @@ __global__ __launch_bounds__(256) void k_fir420(fir_args a)
 /* ---- launch helpers (called from h2y_api.hip) --------------------------- */
 typedef void (*fused_fn)(fused_args);
 
-template <int IN_KIND, int OUT_KIND> static fused_fn pick_mode(int mode)
+template <int IN_KIND, int OUT_KIND, int MODE> static fused_fn pick_pipe(int pipe)
+{
+    switch (pipe) {
+    case H2Y_PIPE_PQ_IDENT: return k_fused<IN_KIND, OUT_KIND, MODE, H2Y_PIPE_PQ_IDENT>;
+    case H2Y_PIPE_PQ_NORM: return k_fused<IN_KIND, OUT_KIND, MODE, H2Y_PIPE_PQ_NORM>;
+    default: return k_fused<IN_KIND, OUT_KIND, MODE, H2Y_PIPE_RUNTIME>;
+    }
+}
+template <int IN_KIND, int OUT_KIND> static fused_fn pick_mode(int mode, int pipe)
 {
     switch (mode) {
-    case H2Y_MODE_YCBCR: return k_fused<IN_KIND, OUT_KIND, H2Y_MODE_YCBCR>;
-    case H2Y_MODE_YDZDX: return k_fused<IN_KIND, OUT_KIND, H2Y_MODE_YDZDX>;
-    default: return k_fused<IN_KIND, OUT_KIND, H2Y_MODE_RUNTIME>;
+    case H2Y_MODE_YCBCR: return pick_pipe<IN_KIND, OUT_KIND, H2Y_MODE_YCBCR>(pipe);
+    case H2Y_MODE_YDZDX: return pick_pipe<IN_KIND, OUT_KIND, H2Y_MODE_YDZDX>(pipe);
+    default: return k_fused<IN_KIND, OUT_KIND, H2Y_MODE_RUNTIME, H2Y_PIPE_RUNTIME>; /* identity / Y100 / Y500: generic */
     }
 }
-template <int IN_KIND> static fused_fn pick_out(int out_kind, int mode, bool narrow)
+template <int IN_KIND> static fused_fn pick_out(const fused_variant &v)
 {
-    if (narrow) return out_kind == H2Y_OUT_444 ? k_fused_narrow<IN_KIND, H2Y_OUT_444> : k_fused_narrow<IN_KIND, H2Y_OUT_444TMP>;
-    switch (out_kind) {
-    case H2Y_OUT_420BOX: return pick_mode<IN_KIND, H2Y_OUT_420BOX>(mode);
-    case H2Y_OUT_444: return pick_mode<IN_KIND, H2Y_OUT_444>(mode);
-    default: return pick_mode<IN_KIND, H2Y_OUT_444TMP>(mode);
+    if (v.narrow) return v.out_kind == H2Y_OUT_444 ? k_fused_narrow<IN_KIND, H2Y_OUT_444> : k_fused_narrow<IN_KIND, H2Y_OUT_444TMP>;
+    switch (v.out_kind) {
+    case H2Y_OUT_420BOX: return pick_mode<IN_KIND, H2Y_OUT_420BOX>(v.mode, v.pipe);
+    case H2Y_OUT_444: return pick_mode<IN_KIND, H2Y_OUT_444>(v.mode, v.pipe);
+    default: return pick_mode<IN_KIND, H2Y_OUT_444TMP>(v.mode, v.pipe);
     }
 }
-static fused_fn pick_fused(int in_kind, int out_kind, int mode, bool narrow)
+static fused_fn pick_fused(const fused_variant &v)
 {
-    switch (in_kind) {
-    case H2Y_IN_F32: return pick_out<H2Y_IN_F32>(out_kind, mode, narrow);
-    case H2Y_IN_F16: return pick_out<H2Y_IN_F16>(out_kind, mode, narrow);
-    default: return pick_out<H2Y_IN_U16>(out_kind, mode, narrow);
+    switch (v.in_kind) {
+    case H2Y_IN_F32: return pick_out<H2Y_IN_F32>(v);
+    case H2Y_IN_F16: return pick_out<H2Y_IN_F16>(v);
+    default: return pick_out<H2Y_IN_U16>(v);
     }
 }
 
 /* resident blocks per CU for this variant (the grid is sized to exactly fill the chip) */
-int h2y_fused_blocks_per_cu(int in_kind, int out_kind, int mode, bool narrow)
+int h2y_fused_blocks_per_cu(const fused_variant &v)
 {
     int nb = 0;
-    fused_fn fn = pick_fused(in_kind, out_kind, mode, narrow);
+    fused_fn fn = pick_fused(v);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(fn), H2Y_FUSED_THREADS, 0) != hipSuccess || nb < 1)
         nb = 1;
     return nb;
 }
 
-hipError_t h2y_launch_fused(int in_kind, int out_kind, int mode, bool narrow, int grid, hipStream_t st, const fused_args &a)
+hipError_t h2y_launch_fused(const fused_variant &v, int grid, hipStream_t st, const fused_args &a)
 {
-    fused_fn fn = pick_fused(in_kind, out_kind, mode, narrow);
+    fused_fn fn = pick_fused(v);
     hipLaunchKernelGGL(fn, dim3(grid), dim3(H2Y_FUSED_THREADS), 0, st, a);
     return hipGetLastError();
 }

@@ -310,34 +310,47 @@ H2Y_FN bool pq_ambiguous(double v)
     return dist < 2u * H2Y_PQ_AMBIG_ULPS;
 }
 
-/* Fast tier.  Returns the float value; *slow is set when the caller must use
- * pq_slow(x) instead (x outside the table, or rounding too close to call). */
-H2Y_FN float pq_fast(float x, const pq_recA *__restrict__ A, const pq_recB *__restrict__ B, bool *slow)
-{
-    const uint32_t bits = f2bits(x);
-    const uint32_t off = pq_rec_offset(bits);
-    /* (B is A + H2Y_PQ_NREC records in the kernels' LDS image: one address register,
-     * the second load uses the instruction's immediate offset) */
-    /* one 16-byte load per record (ds_read_b128 when the table is in LDS) */
+/* Fast tier, split so that a caller can issue the table loads of several
+ * samples before it consumes any of them (LDS latency is the bottleneck of
+ * this tier): pq_fetch() does the two 16-byte loads, pq_eval() the arithmetic. */
 #if defined(__clang__)
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #else
-    struct alignas(16) u32x4 {
-        uint32_t x, y, z, w;
-    };
+struct alignas(16) u32x4 {
+    uint32_t x, y, z, w;
+};
 #endif
-    const u32x4 ra = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(A) + off);
-    const u32x4 rb = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(B) + off);
+struct pq_rec {
+    u32x4 ra, rb; /* raw pq_recA / pq_recB */
+};
+H2Y_FN pq_rec pq_fetch(float x, const pq_recA *__restrict__ A, const pq_recB *__restrict__ B)
+{
+    const uint32_t off = pq_rec_offset(f2bits(x));
+    /* (B is A + H2Y_PQ_NREC records in the kernels' LDS image: one address
+     * register, the second load uses the instruction's immediate offset) */
+    pq_rec r;
+    r.ra = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(A) + off);
+    r.rb = *reinterpret_cast<const u32x4 *>(reinterpret_cast<const char *>(B) + off);
+    return r;
+}
+H2Y_FN float pq_eval(float x, const pq_rec &r, bool *slow)
+{
     pq_recA a;
     pq_recB b;
-    a.c0 = bits2d((uint64_t)ra.x | ((uint64_t)ra.y << 32));
-    a.c1 = bits2d((uint64_t)ra.z | ((uint64_t)ra.w << 32));
-    b.c2 = bits2d((uint64_t)rb.x | ((uint64_t)rb.y << 32));
-    b.c3 = bits2f(rb.z);
-    b.c4 = bits2f(rb.w);
-    const double v = pq_poly(bits, a, b);
+    a.c0 = bits2d((uint64_t)r.ra.x | ((uint64_t)r.ra.y << 32));
+    a.c1 = bits2d((uint64_t)r.ra.z | ((uint64_t)r.ra.w << 32));
+    b.c2 = bits2d((uint64_t)r.rb.x | ((uint64_t)r.rb.y << 32));
+    b.c3 = bits2f(r.rb.z);
+    b.c4 = bits2f(r.rb.w);
+    const double v = pq_poly(f2bits(x), a, b);
     *slow = pq_ambiguous(v);
     return (float)v;
+}
+/* Returns the float value; *slow is set when the caller must use pq_slow(x)
+ * instead (x outside the table, or rounding too close to call). */
+H2Y_FN float pq_fast(float x, const pq_recA *__restrict__ A, const pq_recB *__restrict__ B, bool *slow)
+{
+    return pq_eval(x, pq_fetch(x, A, B), slow);
 }
 
 /* Host-side table builder (context creation).  Per segment: interpolate the

@@ -62,6 +62,7 @@ struct h2y_ctx {
     int n_cu = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     void *d_table = nullptr;
+    float *d_lut16 = nullptr; /* PQ10000_r of every half in [0,2), built on the device at creation */
     /* per-batch device arrays */
     frame_io *d_frames = nullptr, *h_frames = nullptr;
     size_t frames_cap = 0;
@@ -236,6 +237,8 @@ fused_variant pick_variant(const h2y_desc *d, const pix_params &pp, int out_kind
         bool ident = known != nullptr;
         for (int c = 0; c < 3 && ident; c++) ident = known->floor_[c] == 0 && known->ceil_[c] == 1;
         v.pipe = ident ? 1 : 2; /* 2 is always valid: (x - 0) / 1 == x exactly */
+        /* half input with the identity normalisation: the whole transfer is a 64 KB table */
+        if (ident && v.in_kind == H2Y_IN_F16 && (pp.mode == H2Y_MODE_YCBCR || pp.mode == H2Y_MODE_YDZDX)) v.pipe = 3;
     }
     return v;
 }
@@ -287,6 +290,7 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         a.tiles_per_frame = g.tiles;
         a.chunks_per_frame = g.chunks;
         a.table = ctx->d_table;
+        a.lut16 = ctx->d_lut16;
         a.partial = ctx->d_partial;
         a.assumed = d_assumed;
         a.pp = pp;
@@ -473,6 +477,9 @@ int h2y_ctx_create(int device, h2y_ctx **out)
         ctx->d_table = t;
         HIP_TRY(ctx, hipMemcpy(t, A.data(), H2Y_PQ_NREC * 16, hipMemcpyHostToDevice));
         HIP_TRY(ctx, hipMemcpy(t + H2Y_PQ_NREC * 16, B.data(), H2Y_PQ_NREC * 16, hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_lut16, H2Y_LUT16_N * sizeof(float)));
+        HIP_TRY(ctx, h2y_launch_build_lut16(ctx->stream, ctx->d_table, ctx->d_lut16));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_assumed, 2 * sizeof(assumed_stats)));
     HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_assumed, 2 * sizeof(assumed_stats), hipHostMallocDefault));
@@ -492,6 +499,7 @@ void h2y_ctx_destroy(h2y_ctx *ctx)
         if (ctx->ev[i][1]) (void)hipEventDestroy(ctx->ev[i][1]);
     }
     (void)hipFree(ctx->d_table);
+    (void)hipFree(ctx->d_lut16);
     (void)hipFree(ctx->d_frames);
     (void)hipHostFree(ctx->h_frames);
     (void)hipFree(ctx->d_partial);
@@ -747,6 +755,7 @@ int h2y_matrix_convert(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3
     a.tiles_per_frame = g.tiles;
     a.chunks_per_frame = g.chunks;
     a.table = ctx->d_table;
+    a.lut16 = ctx->d_lut16;
     a.partial = ctx->d_partial;
     a.assumed = ctx->d_assumed;
     a.pp = pp;

@@ -15,6 +15,8 @@
 #define H2Y_FUSED_MINWAVES 4 /* waves per SIMD the fused kernel is register-budgeted for: 2 blocks of 512 per CU */
 #endif
 
+#define H2Y_LUT16_N 16384 /* halves 0x0000..0x3FFF = [0, 2) */
+
 enum { H2Y_IN_F32 = 0, H2Y_IN_F16 = 1, H2Y_IN_U16 = 2 };
 enum { H2Y_OUT_420BOX = 0, H2Y_OUT_444 = 1, H2Y_OUT_444TMP = 2 };
 
@@ -51,7 +53,8 @@ struct fused_args {
     uint32_t wq_magic;        /* floor(2^32 / wq) */
     uint32_t tiles_per_frame; /* thread-tiles per frame */
     uint32_t chunks_per_frame;
-    const void *table;        /* pq_recA[NSEG] then pq_recB[NSEG] */
+    const void *table;        /* pq_recA[NREC] then pq_recB[NREC] */
+    const float *lut16;       /* k_fused_lut16: PQ of every half in [0,2) */
     float *partial;           /* [n_frames][grid][6] */
     const assumed_stats *assumed;
     h2y::pix_params pp;       /* offset/range/norm_identity are filled in-kernel from *assumed */
@@ -60,7 +63,8 @@ struct fused_args {
 /* which instantiation of the fused kernel */
 struct fused_variant {
     int in_kind, out_kind, mode;
-    int pipe;      /* 0 runtime flags, 1 LINEAR->PQ with floor 0/ceiling 1, 2 LINEAR->PQ general normalisation */
+    int pipe;      /* 0 runtime flags, 1 LINEAR->PQ with floor 0/ceiling 1, 2 LINEAR->PQ general normalisation,
+                      3 as 1 for half input through the 16 384-entry table (k_fused_lut16) */
     bool narrow;   /* width % 4 != 0: scalar-load variant */
 };
 
@@ -92,6 +96,7 @@ struct fir_args {
 
 int h2y_fused_blocks_per_cu(const fused_variant &v);
 hipError_t h2y_launch_fused(const fused_variant &v, int grid, hipStream_t st, const fused_args &a);
+hipError_t h2y_launch_build_lut16(hipStream_t st, const void *table, float *lut);
 hipError_t h2y_launch_stats(int in_kind, int grid, hipStream_t st, const stats_args &a);
 hipError_t h2y_launch_stats_final(int n_frames, hipStream_t st, const final_args &a);
 hipError_t h2y_launch_fir420(hipStream_t st, const fir_args &a);

@@ -337,10 +337,14 @@ __device__ __forceinline__ void tile_store(const frame_io &io, const tile_pos &t
     }
 }
 
-/* exact tier for one tile: pixel by pixel, each with its own (rarely taken)
- * branch to the careful tier.  (A single straight-line block for all eight
- * pixels with one branch at the end was tried: the register allocator then
- * spills and the kernel is slower.) */
+/* exact tier for one tile.  Pixels are taken two at a time (the two rows of
+ * one column): the fast tier of both is one straight line of code, so six
+ * samples' table loads are in flight together, and one rarely-taken branch
+ * covers the careful tier of the pair.  (One block for all eight pixels makes
+ * the register allocator spill; one pixel at a time exposes the LDS latency.) */
+#ifndef H2Y_PAIR
+#define H2Y_PAIR 1
+#endif
 template <int OUT_KIND, int MODE, int PIPE>
 __device__ __forceinline__ void tile_exact(const pix_params &pp, const pix_params *spp, const pq_recA *sA, const pq_recB *sB,
                                            tile_in &v, tile_out &o)
@@ -348,6 +352,26 @@ __device__ __forceinline__ void tile_exact(const pix_params &pp, const pix_param
 #pragma unroll
     for (int jb = 0; jb < 2; jb++) {
         uint32_t Y[4], Cb[4], Cr[4];
+#if H2Y_PAIR
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const int col = 2 * jb + c;
+            const float G0 = norm1<PIPE>(pp, 0, v.g0[col]), B0 = norm1<PIPE>(pp, 1, v.b0[col]), R0 = norm1<PIPE>(pp, 2, v.r0[col]);
+            const float G1 = norm1<PIPE>(pp, 0, v.g1[col]), B1 = norm1<PIPE>(pp, 1, v.b1[col]), R1 = norm1<PIPE>(pp, 2, v.r1[col]);
+            const bool u0 = pixel_fast<MODE, PIPE>(pp, sA, sB, G0, B0, R0, Y[c], Cb[c], Cr[c]);
+            const bool u1 = pixel_fast<MODE, PIPE>(pp, sA, sB, G1, B1, R1, Y[2 + c], Cb[2 + c], Cr[2 + c]);
+            if (__builtin_expect(u0 | u1, 0)) {
+                if (u0) {
+                    const ycc k = pixel_careful<MODE>(spp, G0, B0, R0);
+                    Y[c] = k.y; Cb[c] = k.cb; Cr[c] = k.cr;
+                }
+                if (u1) {
+                    const ycc k = pixel_careful<MODE>(spp, G1, B1, R1);
+                    Y[2 + c] = k.y; Cb[2 + c] = k.cb; Cr[2 + c] = k.cr;
+                }
+            }
+        }
+#else
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int col = 2 * jb + (q & 1);
@@ -355,12 +379,11 @@ __device__ __forceinline__ void tile_exact(const pix_params &pp, const pix_param
             const float B = norm1<PIPE>(pp, 1, q < 2 ? v.b0[col] : v.b1[col]);
             const float R = norm1<PIPE>(pp, 2, q < 2 ? v.r0[col] : v.r1[col]);
             if (__builtin_expect(pixel_fast<MODE, PIPE>(pp, sA, sB, G, B, R, Y[q], Cb[q], Cr[q]), 0)) {
-                const ycc c = pixel_careful<MODE>(spp, G, B, R);
-                Y[q] = c.y;
-                Cb[q] = c.cb;
-                Cr[q] = c.cr;
+                const ycc k = pixel_careful<MODE>(spp, G, B, R);
+                Y[q] = k.y; Cb[q] = k.cb; Cr[q] = k.cr;
             }
         }
+#endif
         tile_pack<OUT_KIND>(pp, jb, Y, Cb, Cr, o);
     }
 }
@@ -422,6 +445,126 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
         }
         block_store_mm<H2Y_FUSED_THREADS / WAVE>(mm, s_red, a.partial + ((size_t)f * G + blockIdx.x) * 6);
     }
+}
+
+/*
+ * k_fused_lut16: half-float input (EXR, exr.cpp:233), LINEAR -> PQ, floor 0 /
+ * ceiling 1.  A half in [0, 2) has only 16 384 bit patterns, so PQ10000_r() of
+ * every one of them fits in LDS (64 KB of binary32, built once per context by
+ * k_build_lut16 with the exact tiers): the per-sample transfer is one 4-byte LDS
+ * read, exact by construction, zero included.  Samples outside [0, 2) (sign or
+ * bit 14 set) send their pixel to the careful tier.  Everything after the
+ * transfer is the same arithmetic as k_fused.  min/max for pic_stats run on
+ * the packed halves (v_pk_min_f16 / v_pk_max_f16 order halves exactly as their
+ * widened floats).
+ */
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_min_h(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_min_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t pk_max_h(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ float half_bits_to_float(uint32_t h) { return (float)__builtin_bit_cast(_Float16, (uint16_t)h); }
+
+template <int OUT_KIND, int MODE>
+__global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused_lut16(fused_args a)
+{
+    __shared__ float s_lut[H2Y_LUT16_N];
+    __shared__ float s_red[(H2Y_FUSED_THREADS / WAVE) * 6];
+    __shared__ pix_params s_pp;
+    {
+        const uint4 *g = reinterpret_cast<const uint4 *>(a.lut16);
+        uint4 *l = reinterpret_cast<uint4 *>(s_lut);
+        for (int i = threadIdx.x; i < H2Y_LUT16_N / 4; i += H2Y_FUSED_THREADS) l[i] = g[i];
+    }
+    const pix_params pp = with_assumed(a.pp, a.assumed);
+    if (threadIdx.x == 0) s_pp = pp;
+    __syncthreads();
+
+    const uint32_t W = a.width, H = a.height, G = gridDim.x;
+    for (int f = 0; f < a.n_frames; f++) {
+        const frame_io io = a.frames[f];
+        /* packed-half accumulators: {min, max} x plane, two halves per dword */
+        uint32_t mn[3], mx[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            mn[c] = 0x7C007C00u; /* +inf stands in for FLT_MAX (common.cpp:118): no finite or infinite sample is "< FLT_MAX" unless it is finite */
+            mx[c] = 0x00000000u; /* +0: FLT_MIN (1.2e-38) is below the smallest half; (int) of either is 0 */
+        }
+        const uint32_t gbase = (uint32_t)(((uint64_t)f * a.chunks_per_frame) % G);
+        uint32_t k = (blockIdx.x + G - gbase) % G;
+        for (; k < a.chunks_per_frame; k += G) {
+            const uint32_t tt = k * H2Y_FUSED_THREADS + threadIdx.x;
+            if (tt >= a.tiles_per_frame) continue;
+            const tile_pos t = tile_locate(tt, W, H, a.wq, a.wq_magic);
+            /* raw halves: [plane][row] as two dwords (4 samples) */
+            uint2 raw[3][2];
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                raw[c][0] = *reinterpret_cast<const uint2 *>(static_cast<const uint16_t *>(io.in[c]) + t.i0);
+                raw[c][1] = *reinterpret_cast<const uint2 *>(static_cast<const uint16_t *>(io.in[c]) + t.i1);
+                mn[c] = pk_min_h(pk_min_h(mn[c], raw[c][0].x), pk_min_h(raw[c][0].y, pk_min_h(raw[c][1].x, raw[c][1].y)));
+                mx[c] = pk_max_h(pk_max_h(mx[c], raw[c][0].x), pk_max_h(raw[c][0].y, pk_max_h(raw[c][1].x, raw[c][1].y)));
+            }
+            tile_out o;
+#pragma unroll
+            for (int jb = 0; jb < 2; jb++) {
+                uint32_t Y[4], Cb[4], Cr[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int row = q >> 1, hi = q & 1; /* column 2*jb + hi of the tile */
+                    const uint32_t wg = jb ? raw[0][row].y : raw[0][row].x;
+                    const uint32_t wb = jb ? raw[1][row].y : raw[1][row].x;
+                    const uint32_t wr = jb ? raw[2][row].y : raw[2][row].x;
+                    const uint32_t hg = hi ? wg >> 16 : wg & 0xFFFFu, hb = hi ? wb >> 16 : wb & 0xFFFFu, hr = hi ? wr >> 16 : wr & 0xFFFFu;
+                    const float g = pix_scale(s_lut[hg & (H2Y_LUT16_N - 1)], pp.mulY, pp.addY);
+                    const float b = pix_scale(s_lut[hb & (H2Y_LUT16_N - 1)], pp.mulC, pp.addC);
+                    const float r = pix_scale(s_lut[hr & (H2Y_LUT16_N - 1)], pp.mulC, pp.addC);
+                    bool um;
+                    pix_matrix<MODE, false>(pp, g, b, r, Y[q], Cb[q], Cr[q], &um);
+                    const bool outside = ((hg | hb | hr) & ~(uint32_t)(H2Y_LUT16_N - 1)) != 0; /* negative, >= 2.0, inf, NaN */
+                    if (__builtin_expect(outside | um, 0)) {
+                        const ycc c = pixel_careful<MODE>(&s_pp, half_bits_to_float(hg), half_bits_to_float(hb), half_bits_to_float(hr));
+                        Y[q] = c.y; Cb[q] = c.cb; Cr[q] = c.cr;
+                    }
+                }
+                tile_pack<OUT_KIND>(pp, jb, Y, Cb, Cr, o);
+            }
+            tile_store<OUT_KIND>(io, t, W, H, o);
+        }
+        mm6 mm;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            /* fold the two packed halves, widen; floats from here on (block_store_mm) */
+            mm.lo[c] = fminf(half_bits_to_float(mn[c] & 0xFFFFu), half_bits_to_float(mn[c] >> 16));
+            mm.hi[c] = fmaxf(half_bits_to_float(mx[c] & 0xFFFFu), half_bits_to_float(mx[c] >> 16));
+            /* restore pic_stats' initial values when nothing beat them */
+            mm.lo[c] = mm.lo[c] > 65504.0f ? 3.402823466e+38f : mm.lo[c]; /* still +inf: no sample was below FLT_MAX */
+            mm.hi[c] = mm.hi[c] <= 0.0f ? 1.175494351e-38f : mm.hi[c];
+        }
+        block_store_mm<H2Y_FUSED_THREADS / WAVE>(mm, s_red, a.partial + ((size_t)f * G + blockIdx.x) * 6);
+    }
+}
+
+/* PQ10000_r() of every half in [0, 2) through the exact tiers; table records read from HBM */
+__global__ __launch_bounds__(256) void k_build_lut16(const void *table, float *lut)
+{
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= H2Y_LUT16_N) return;
+    const pq_recA *A = static_cast<const pq_recA *>(table);
+    const pq_recB *B = reinterpret_cast<const pq_recB *>(A + H2Y_PQ_NREC);
+    const float x = half_bits_to_float(h);
+    bool slow;
+    float v = pq_fast(x, A, B, &slow);
+    if (slow) v = pq_slow(x);
+    lut[h] = v;
 }
 
 /*
@@ -586,44 +729,90 @@ __global__ __launch_bounds__(256) void k_box420(const uint16_t *__restrict__ src
 #define FIR_TH 16
 #define FIR_ROWS (2 * FIR_TH + 10)
 #define FIR_COLS (2 * FIR_TW + 10)
+#define FIR_LCOLS (2 * FIR_TW + 16) /* staged columns: 8 left of the tile (16-byte aligned), 8 right */
 
 __global__ __launch_bounds__(256) void k_fir420(fir_args a)
 {
-    __shared__ uint16_t s444[FIR_ROWS][FIR_COLS + 2];
-    __shared__ uint16_t s422[FIR_ROWS][FIR_TW];
+    /* 4:4:4 source rows 2*r0-5 .. 2*r0+36, columns 2*c0-8 .. 2*c0+135 (16-byte aligned start) */
+    __shared__ __attribute__((aligned(16))) uint16_t s444[FIR_ROWS][FIR_LCOLS];
+    __shared__ __attribute__((aligned(16))) uint16_t s422[FIR_ROWS][FIR_TW];
     const int W = a.width, H = a.height, wc = W >> 1, hc = H >> 1;
     const uint16_t *src = blockIdx.z == 0 ? a.src_cb : a.src_cr;
     uint16_t *dst = blockIdx.z == 0 ? a.dst_cb : a.dst_cr;
     const int c0 = blockIdx.x * FIR_TW, r0 = blockIdx.y * FIR_TH;
-    const int ys = 2 * r0 - 5, xs = 2 * c0 - 5;
+    const int ys = 2 * r0 - 5, xs = 2 * c0 - 8;
 
-    for (int i = threadIdx.x; i < FIR_ROWS * FIR_COLS; i += 256) {
-        int r = i / FIR_COLS, c = i - r * FIR_COLS;
-        int y = min(max(ys + r, 0), H - 1), x = min(max(xs + c, 0), W - 1);
-        s444[r][c] = src[(size_t)y * W + x];
+    /* 1. stage the source tile; rows and columns outside the picture replicate the edge
+     *    (the reference's clamped indices, convert.cpp:295-300 and :337-347) */
+    const bool interior = xs >= 0 && xs + FIR_LCOLS <= W && (W & 7) == 0 && ((uintptr_t)src & 15) == 0;
+    if (interior) {
+        for (int i = threadIdx.x; i < FIR_ROWS * (FIR_LCOLS / 8); i += 256) {
+            const int r = i / (FIR_LCOLS / 8), c8 = i - r * (FIR_LCOLS / 8);
+            const int y = min(max(ys + r, 0), H - 1);
+            *reinterpret_cast<uint4 *>(&s444[r][c8 * 8]) = *reinterpret_cast<const uint4 *>(src + (size_t)y * W + xs + c8 * 8);
+        }
+    } else {
+        for (int i = threadIdx.x; i < FIR_ROWS * FIR_LCOLS; i += 256) {
+            const int r = i / FIR_LCOLS, c = i - r * FIR_LCOLS;
+            const int y = min(max(ys + r, 0), H - 1), x = min(max(xs + c, 0), W - 1);
+            s444[r][c] = src[(size_t)y * W + x];
+        }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < FIR_ROWS * FIR_TW; i += 256) {
-        int r = i / FIR_TW, c = i - r * FIR_TW;
-        const uint16_t *s = &s444[r][2 * c]; /* s[5] is the even column 2*(c0+c) */
-        /* In-picture rows only matter; out-of-picture rows were replicated
-         * from the edge row, giving the same 4:2:2 value the reference reads
-         * through its clamped row index. */
-        s422[r][c] = (uint16_t)fir_h((float)s[0], (float)s[2], (float)s[4], (float)s[5], (float)s[6], (float)s[8],
-                                     (float)s[10], a.fir_max);
+
+    /* 2. horizontal 7-tap at the even columns -> u16 4:2:2 tile (clamped and truncated exactly as
+     *    the reference stores dst422, convert.cpp:314-317).  One item = one row x 8 outputs:
+     *    32 source samples from four 16-byte LDS reads. */
+    for (int i = threadIdx.x; i < FIR_ROWS * (FIR_TW / 8); i += 256) {
+        const int r = i / (FIR_TW / 8), g = i - r * (FIR_TW / 8);
+        uint32_t w[16];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint4 t = *reinterpret_cast<const uint4 *>(&s444[r][16 * g + 8 * q]);
+            w[4 * q] = t.x; w[4 * q + 1] = t.y; w[4 * q + 2] = t.z; w[4 * q + 3] = t.w;
+        }
+        float s[32];
+#pragma unroll
+        for (int q = 0; q < 16; q++) {
+            s[2 * q] = (float)(w[q] & 0xFFFFu);
+            s[2 * q + 1] = (float)(w[q] >> 16);
+        }
+        uint32_t o[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int ctr = 8 + 2 * j; /* local index of the even column 2*(c0 + 8g + j) */
+            o[j] = fir_h(s[ctr - 5], s[ctr - 3], s[ctr - 1], s[ctr], s[ctr + 1], s[ctr + 3], s[ctr + 5], a.fir_max);
+        }
+        *reinterpret_cast<uint4 *>(&s422[r][8 * g]) =
+            make_uint4(o[0] | (o[1] << 16), o[2] | (o[3] << 16), o[4] | (o[5] << 16), o[6] | (o[7] << 16));
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < FIR_TH * FIR_TW; i += 256) {
-        int r = i / FIR_TW, c = i - r * FIR_TW;
-        int yo = r0 + r, xo = c0 + c;
+
+    /* 3. vertical 12-tap (convert.cpp:365-374), then write_yuv's shift + range clamp.
+     *    One item = one output row x 4 outputs. */
+    for (int i = threadIdx.x; i < FIR_TH * (FIR_TW / 4); i += 256) {
+        const int r = i / (FIR_TW / 4), g = i - r * (FIR_TW / 4);
+        const int yo = r0 + r, xo = c0 + 4 * g;
         if (yo >= hc || xo >= wc) continue;
-        const int b = 2 * r; /* s422 row of source row 2*yo-5 */
-        uint32_t v = fir_v((float)s422[b][c], (float)s422[b + 1][c], (float)s422[b + 2][c], (float)s422[b + 3][c],
-                           (float)s422[b + 4][c], (float)s422[b + 5][c], (float)s422[b + 6][c], (float)s422[b + 7][c],
-                           (float)s422[b + 8][c], (float)s422[b + 9][c], (float)s422[b + 10][c], (float)s422[b + 11][c],
-                           a.fir_max);
-        if (a.apply_yuv_clamp) v = pix_yuv_clamp(a.pp, v, true);
-        dst[(size_t)yo * wc + xo] = (uint16_t)v;
+        float t[12][4];
+#pragma unroll
+        for (int k = 0; k < 12; k++) {
+            const uint2 q = *reinterpret_cast<const uint2 *>(&s422[2 * r + k][4 * g]);
+            t[k][0] = (float)(q.x & 0xFFFFu); t[k][1] = (float)(q.x >> 16);
+            t[k][2] = (float)(q.y & 0xFFFFu); t[k][3] = (float)(q.y >> 16);
+        }
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t v = fir_v(t[0][j], t[1][j], t[2][j], t[3][j], t[4][j], t[5][j], t[6][j], t[7][j], t[8][j], t[9][j], t[10][j],
+                               t[11][j], a.fir_max);
+            if (a.apply_yuv_clamp) v = pix_yuv_clamp(a.pp, v, true);
+            o[j] = v;
+        }
+        uint16_t *d = dst + (size_t)yo * wc + xo;
+        if (xo + 3 < wc && (((uintptr_t)d) & 7) == 0) *reinterpret_cast<uint2 *>(d) = make_uint2(o[0] | (o[1] << 16), o[2] | (o[3] << 16));
+        else
+            for (int j = 0; j < 4 && xo + j < wc; j++) d[j] = (uint16_t)o[j];
     }
 }
 
@@ -655,8 +844,19 @@ template <int IN_KIND> static fused_fn pick_out(const fused_variant &v)
     default: return pick_mode<IN_KIND, H2Y_OUT_444TMP>(v.mode, v.pipe);
     }
 }
+template <int OUT_KIND> static fused_fn pick_lut_mode(int mode)
+{
+    return mode == H2Y_MODE_YCBCR ? k_fused_lut16<OUT_KIND, H2Y_MODE_YCBCR> : k_fused_lut16<OUT_KIND, H2Y_MODE_YDZDX>;
+}
 static fused_fn pick_fused(const fused_variant &v)
 {
+    if (v.pipe == 3) {
+        switch (v.out_kind) {
+        case H2Y_OUT_420BOX: return pick_lut_mode<H2Y_OUT_420BOX>(v.mode);
+        case H2Y_OUT_444: return pick_lut_mode<H2Y_OUT_444>(v.mode);
+        default: return pick_lut_mode<H2Y_OUT_444TMP>(v.mode);
+        }
+    }
     switch (v.in_kind) {
     case H2Y_IN_F32: return pick_out<H2Y_IN_F32>(v);
     case H2Y_IN_F16: return pick_out<H2Y_IN_F16>(v);
@@ -678,6 +878,12 @@ hipError_t h2y_launch_fused(const fused_variant &v, int grid, hipStream_t st, co
 {
     fused_fn fn = pick_fused(v);
     hipLaunchKernelGGL(fn, dim3(grid), dim3(H2Y_FUSED_THREADS), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t h2y_launch_build_lut16(hipStream_t st, const void *table, float *lut)
+{
+    hipLaunchKernelGGL(k_build_lut16, dim3(H2Y_LUT16_N / 256), dim3(256), 0, st, table, lut);
     return hipGetLastError();
 }
 

@@ -282,3 +282,73 @@ def test_cli_writes_reference_bytes(tmp_path):
         data = open(out, "rb").read()
         assert len(data) == 6144 * n
         assert hashlib.md5(data[-6144:]).hexdigest() == KNOWN["cases"]["tiny_64x32_2020_10b_fir"]["md5"]
+
+
+def test_f16_table_path_batch(ctx, oracle):
+    """Half input through h2y_convert_batch with known floor 0 / ceiling 1 takes the
+    16 384-entry table kernel (k_fused_lut16): zero, subnormal halves, 1.0, and
+    overshoot values >= 2.0 (which leave the table and go to the careful tier)."""
+    import torch
+
+    rng = np.random.default_rng(31)
+    w, hh = 256, 64
+    frames = []
+    for k in range(3):
+        planes = [rng.uniform(0, 1, w * hh).astype(np.float16) for _ in range(3)]
+        for p in planes:
+            p[0], p[1] = 0.0, 1.0
+            p[2:8] = np.array([5.96e-8, 6.0e-5, 1.5, 1.999, 1e-3, 0.0], np.float16)
+        if k == 1:  # overshoot, still (int)max == 1
+            planes[0][100] = np.float16(1.9)
+        frames.append([p.view(np.uint16) for p in planes])
+    for (mat, depth, chroma, res) in ((h.MATRIX_BT2020NC, 10, h.CHROMA_420, 0), (h.MATRIX_YDZDX, 16, h.CHROMA_444, 0),
+                                      (h.MATRIX_BT709, 12, h.CHROMA_420, 1)):
+        d = h.make_desc(w, hh, sample=h.SAMPLE_F16, dst_depth=depth, dst_matrix=mat, chroma=chroma, resampler=res,
+                        stats=[(0, 1)] * 3)
+        dev_in = [[torch.from_numpy(p.view(np.int16)).cuda() for p in fr] for fr in frames]
+        dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda") for _ in frames]
+        torch.cuda.synchronize()
+        ctx.convert_batch(d, dev_in, dev_out)
+        od = _to_oracle_desc(d)
+        for f in range(len(frames)):
+            assert np.array_equal(dev_out[f].cpu().numpy().view(np.uint16), oracle.convert_frame(od, frames[f])), (mat, f)
+    # values >= 2.0 with an override: outside the table, careful tier, still exact
+    planes = [rng.uniform(0, 4, w * hh).astype(np.float16).view(np.uint16) for _ in range(3)]
+    d = h.make_desc(w, hh, sample=h.SAMPLE_F16, dst_depth=12, dst_matrix=h.MATRIX_BT2020NC, resampler=0, stats=[(0, 1)] * 3)
+    dev_in = [[torch.from_numpy(p.view(np.int16)).cuda() for p in planes]]
+    dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda")]
+    torch.cuda.synchronize()
+    ctx.convert_batch(d, dev_in, dev_out)
+    assert np.array_equal(dev_out[0].cpu().numpy().view(np.uint16), oracle.convert_frame(_to_oracle_desc(d), planes))
+    # the hint route (no override): first batch measures, second batch assumes 0/1 and uses the table
+    fresh = h.Context(0)
+    try:
+        d = h.make_desc(w, hh, sample=h.SAMPLE_F16, dst_depth=10, dst_matrix=h.MATRIX_BT2020NC, resampler=0)
+        dev_in = [[torch.from_numpy(p.view(np.int16)).cuda() for p in fr] for fr in frames]
+        for _ in range(2):
+            dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda") for _ in frames]
+            torch.cuda.synchronize()
+            fresh.convert_batch(d, dev_in, dev_out)
+            for f in range(len(frames)):
+                assert np.array_equal(dev_out[f].cpu().numpy().view(np.uint16), oracle.convert_frame(_to_oracle_desc(d), frames[f]))
+    finally:
+        fresh.close()
+
+
+def test_c4_known_md5_through_batch_table_path(ctx, oracle):
+    """C4 (8K half input) at full size through the batch entry with the hint route: md5 of SURVEY 8c."""
+    import torch
+
+    case = KNOWN["cases"]["C4_8k_f16_2020_10b_box"]
+    d = h.make_desc(**case["desc"])
+    planes = oracle.synth_frame(d.width, d.height, 0, f16=True)
+    dev_in = [[torch.from_numpy(p.view(np.int16)).cuda() for p in planes]]
+    fresh = h.Context(0)
+    try:
+        for _ in range(2):
+            dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda")]
+            torch.cuda.synchronize()
+            fresh.convert_batch(d, dev_in, dev_out)
+            assert _md5(dev_out[0].cpu().numpy().view(np.uint16)) == case["md5"]
+    finally:
+        fresh.close()

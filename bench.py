@@ -127,6 +127,7 @@ def main():
     import torch.distributed as dist
 
     import hdr2yuv_amd as h
+    from hdr2yuv_amd.shard import frames_for_rank
     from hdr2yuv_amd.synth import synth_frame
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -156,8 +157,8 @@ def main():
 
     # ---- synthetic input, resident in HBM before any timed region --------
     frames_in = []
-    for k in range(F):
-        planes = synth_frame(w, hh, rank * F + k, f16=f16)
+    for k in frames_for_rank(world * F, rank, world):  # this rank's contiguous block of the global frame sequence
+        planes = synth_frame(w, hh, k, f16=f16)
         frames_in.append([torch.from_numpy(p.view(np.int16) if f16 else p).to(dev) for p in planes])
     ctx = h.Context(local_rank)
 

@@ -352,3 +352,26 @@ def test_c4_known_md5_through_batch_table_path(ctx, oracle):
             assert _md5(dev_out[0].cpu().numpy().view(np.uint16)) == case["md5"]
     finally:
         fresh.close()
+
+
+def test_caller_stream(ctx, oracle):
+    """h2y_ctx_set_stream: launches go to the caller's HIP stream (torch's here)."""
+    import torch
+
+    rng = np.random.default_rng(41)
+    w, hh = 128, 32
+    d = h.make_desc(w, hh, dst_depth=10, dst_matrix=h.MATRIX_BT2020NC, resampler=0)
+    planes = _rand_planes(rng, w, hh, h.SAMPLE_F32)
+    st = torch.cuda.Stream()
+    fresh = h.Context(0)
+    try:
+        fresh.set_stream(st.cuda_stream)
+        with torch.cuda.stream(st):
+            dev_in = [[torch.from_numpy(p).cuda(non_blocking=False) for p in planes]]
+            dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda")]
+        st.synchronize()
+        fresh.convert_batch(d, dev_in, dev_out)
+        assert np.array_equal(dev_out[0].cpu().numpy().view(np.uint16), oracle.convert_frame(_to_oracle_desc(d), planes))
+        fresh.set_stream(None)
+    finally:
+        fresh.close()

@@ -61,6 +61,10 @@ struct h2y_ctx {
     int device = 0;
     int n_cu = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
+    /* FIR pass runs on its own stream so that it overlaps the next sub-batch's fused kernel */
+    hipStream_t fir_stream = nullptr;
+    hipEvent_t ev_fused[2] = {nullptr, nullptr}, ev_fir[2] = {nullptr, nullptr};
+    bool fir_used[2] = {false, false};
     void *d_table = nullptr;
     float *d_lut16 = nullptr; /* PQ10000_r of every half in [0,2), built on the device at creation */
     /* per-batch device arrays */
@@ -261,16 +265,21 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
     const size_t npix = (size_t)d->width * d->height;
     const int step = out_kind == H2Y_OUT_444TMP ? kFirSubBatch : n;
     if (out_kind == H2Y_OUT_444TMP) {
-        int rc = ensure(ctx, ctx->d_tmp, ctx->tmp_cap, (size_t)kFirSubBatch * 2 * npix * sizeof(uint16_t));
+        /* two halves: sub-batch i writes half i%2 while the FIR pass still reads the other */
+        int rc = ensure(ctx, ctx->d_tmp, ctx->tmp_cap, (size_t)2 * kFirSubBatch * 2 * npix * sizeof(uint16_t));
         if (rc) return rc;
     }
-    for (int f0 = 0; f0 < n; f0 += step) {
+    int sub = 0;
+    for (int f0 = 0; f0 < n; f0 += step, sub++) {
         const int nf = (n - f0 < step) ? n - f0 : step;
+        const int half = sub & 1;
+        if (out_kind == H2Y_OUT_444TMP && ctx->fir_used[half]) /* scratch half still being read by an earlier FIR pass? */
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_fir[half], 0));
         /* frame descriptors: host -> device (tiny) */
         for (int i = 0; i < nf; i++) {
             frame_io io = frames[f0 + i];
             if (out_kind == H2Y_OUT_444TMP) {
-                io.tmp_cb = ctx->d_tmp + (size_t)i * 2 * npix;
+                io.tmp_cb = ctx->d_tmp + ((size_t)half * kFirSubBatch + i) * 2 * npix;
                 io.tmp_cr = io.tmp_cb + npix;
             }
             ctx->h_frames[f0 + i] = io;
@@ -312,21 +321,26 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         fa.publish = nullptr;
         HIP_TRY(ctx, h2y_launch_stats_final(nf, ctx->stream, fa));
         if (out_kind == H2Y_OUT_444TMP) {
-            for (int i = 0; i < nf; i++) {
-                fir_args fr;
-                fr.src_cb = ctx->h_frames[f0 + i].tmp_cb;
-                fr.src_cr = ctx->h_frames[f0 + i].tmp_cr;
-                fr.dst_cb = frames[f0 + i].out + npix;
-                fr.dst_cr = fr.dst_cb + (size_t)(d->width >> 1) * (d->height >> 1);
-                fr.width = d->width;
-                fr.height = d->height;
-                fr.fir_max = pp.fir_max;
-                fr.apply_yuv_clamp = 1;
-                fr.pp = pp;
-                HIP_TRY(ctx, h2y_launch_fir420(ctx->stream, fr));
-            }
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_fused[half], ctx->stream));
+            HIP_TRY(ctx, hipStreamWaitEvent(ctx->fir_stream, ctx->ev_fused[half], 0));
+            fir_args fr;
+            fr.frames = ctx->d_frames + f0;
+            fr.n_frames = nf;
+            fr.src_cb = fr.src_cr = nullptr;
+            fr.dst_cb = fr.dst_cr = nullptr;
+            fr.width = d->width;
+            fr.height = d->height;
+            fr.fir_max = pp.fir_max;
+            fr.apply_yuv_clamp = 1;
+            fr.pp = pp;
+            HIP_TRY(ctx, h2y_launch_fir420(ctx->fir_stream, fr));
+            HIP_TRY(ctx, hipEventRecord(ctx->ev_fir[half], ctx->fir_stream));
+            ctx->fir_used[half] = true;
         }
     }
+    if (out_kind == H2Y_OUT_444TMP) /* everything queued after this call on the main stream sees finished chroma */
+        for (int hlf = 0; hlf < 2; hlf++)
+            if (ctx->fir_used[hlf]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_fir[hlf], 0));
     return 0;
 }
 
@@ -463,6 +477,11 @@ int h2y_ctx_create(int device, h2y_ctx **out)
     ctx->n_cu = prop.multiProcessorCount;
     HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
+    HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->fir_stream, hipStreamNonBlocking));
+    for (int i = 0; i < 2; i++) {
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fused[i], hipEventDisableTiming));
+        HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fir[i], hipEventDisableTiming));
+    }
     for (int i = 0; i < kMaxEvents; i++) {
         HIP_TRY(ctx, hipEventCreate(&ctx->ev[i][0]));
         HIP_TRY(ctx, hipEventCreate(&ctx->ev[i][1]));
@@ -510,6 +529,14 @@ void h2y_ctx_destroy(h2y_ctx *ctx)
     (void)hipFree(ctx->d_tmp);
     (void)hipFree(ctx->d_in);
     (void)hipFree(ctx->d_out);
+    if (ctx->fir_stream) {
+        (void)hipStreamSynchronize(ctx->fir_stream);
+        (void)hipStreamDestroy(ctx->fir_stream);
+    }
+    for (int i = 0; i < 2; i++) {
+        if (ctx->ev_fused[i]) (void)hipEventDestroy(ctx->ev_fused[i]);
+        if (ctx->ev_fir[i]) (void)hipEventDestroy(ctx->ev_fir[i]);
+    }
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -777,6 +804,7 @@ int h2y_subsample_420(h2y_ctx *ctx, int width, int height, int bit_depth, int ch
     else {
         fir_args fr;
         memset(&fr, 0, sizeof fr);
+        fr.frames = nullptr;
         fr.src_cb = d_src;
         fr.src_cr = nullptr;
         fr.dst_cb = d_dst;

@@ -86,7 +86,9 @@ struct final_args {
 };
 
 struct fir_args {
-    const uint16_t *src_cb, *src_cr; /* 4:4:4 planes; src_cr may be NULL (one plane) */
+    const frame_io *frames;          /* batch form: n_frames entries (tmp_cb/tmp_cr -> out's chroma planes); else NULL */
+    int n_frames;
+    const uint16_t *src_cb, *src_cr; /* single form: 4:4:4 planes; src_cr may be NULL (one plane) */
     uint16_t *dst_cb, *dst_cr;
     int width, height;
     float fir_max;       /* (float)clip->maxCV of the tmp picture, convert.cpp:314 */

@@ -726,7 +726,7 @@ __global__ __launch_bounds__(256) void k_box420(const uint16_t *__restrict__ src
  *      clamp of write_yuv
  */
 #define FIR_TW 64
-#define FIR_TH 16
+#define FIR_TH 32
 #define FIR_ROWS (2 * FIR_TH + 10)
 #define FIR_COLS (2 * FIR_TW + 10)
 #define FIR_LCOLS (2 * FIR_TW + 16) /* staged columns: 8 left of the tile (16-byte aligned), 8 right */
@@ -737,8 +737,17 @@ __global__ __launch_bounds__(256) void k_fir420(fir_args a)
     __shared__ __attribute__((aligned(16))) uint16_t s444[FIR_ROWS][FIR_LCOLS];
     __shared__ __attribute__((aligned(16))) uint16_t s422[FIR_ROWS][FIR_TW];
     const int W = a.width, H = a.height, wc = W >> 1, hc = H >> 1;
-    const uint16_t *src = blockIdx.z == 0 ? a.src_cb : a.src_cr;
-    uint16_t *dst = blockIdx.z == 0 ? a.dst_cb : a.dst_cr;
+    const uint16_t *src;
+    uint16_t *dst;
+    if (a.frames) { /* batch form: blockIdx.z = 2*frame + plane */
+        const frame_io io = a.frames[blockIdx.z >> 1];
+        uint16_t *cb = io.out + (size_t)W * H;
+        src = (blockIdx.z & 1) ? io.tmp_cr : io.tmp_cb;
+        dst = (blockIdx.z & 1) ? cb + (size_t)wc * hc : cb;
+    } else {
+        src = blockIdx.z == 0 ? a.src_cb : a.src_cr;
+        dst = blockIdx.z == 0 ? a.dst_cb : a.dst_cr;
+    }
     const int c0 = blockIdx.x * FIR_TW, r0 = blockIdx.y * FIR_TH;
     const int ys = 2 * r0 - 5, xs = 2 * c0 - 8;
 
@@ -907,7 +916,7 @@ hipError_t h2y_launch_stats_final(int n_frames, hipStream_t st, const final_args
 hipError_t h2y_launch_fir420(hipStream_t st, const fir_args &a)
 {
     const int wc = a.width >> 1, hc = a.height >> 1;
-    dim3 grid((wc + FIR_TW - 1) / FIR_TW, (hc + FIR_TH - 1) / FIR_TH, a.src_cr ? 2 : 1);
+    dim3 grid((wc + FIR_TW - 1) / FIR_TW, (hc + FIR_TH - 1) / FIR_TH, a.frames ? 2 * a.n_frames : (a.src_cr ? 2 : 1));
     hipLaunchKernelGGL(k_fir420, grid, dim3(256), 0, st, a);
     return hipGetLastError();
 }

@@ -295,19 +295,29 @@ H2Y_FN double pq_poly(uint32_t bits, const pq_recA &a, const pq_recB &b)
     v = __builtin_fma(v, ud, a.c1);
     return __builtin_fma(v, ud, a.c0);
 }
+H2Y_FN uint32_t umin32(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r; /* keep it one v_min_u32: the optimiser otherwise rewrites it as compare + select */
+    asm("v_min_u32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return a < b ? a : b;
+#endif
+}
 /* byte offset of the segment's records; out-of-table inputs (0, tiny, >= 2,
  * negative, NaN) all wrap above the table and are clamped to the sentinel */
 H2Y_FN uint32_t pq_rec_offset(uint32_t bits)
 {
     uint32_t t = bits - (H2Y_PQ_SEG_BASE << H2Y_PQ_LOW_BITS);
-    uint32_t off = (t >> (H2Y_PQ_LOW_BITS - 4)) & ~15u;
-    return off < (uint32_t)H2Y_PQ_NSEG * 16u ? off : (uint32_t)H2Y_PQ_NSEG * 16u;
+    uint32_t idx = umin32(t >> H2Y_PQ_LOW_BITS, (uint32_t)H2Y_PQ_NSEG);
+    return idx << 4;
 }
+/* low 29 bits within AMBIG of the tie at 2^28: shifting left by 3 drops the other bits */
 H2Y_FN bool pq_ambiguous(double v)
 {
     uint32_t lo = (uint32_t)d2bits(v);
-    uint32_t dist = (lo + (H2Y_PQ_AMBIG_ULPS - 0x10000000u)) & 0x1FFFFFFFu;
-    return dist < 2u * H2Y_PQ_AMBIG_ULPS;
+    return ((lo << 3) + ((H2Y_PQ_AMBIG_ULPS - 0x10000000u) << 3)) < ((2u * H2Y_PQ_AMBIG_ULPS) << 3);
 }
 
 /* Fast tier, split so that a caller can issue the table loads of several

@@ -135,6 +135,19 @@ template <typename T> int ensure(h2y_ctx *ctx, T *&p, size_t &cap, size_t need_b
     return 0;
 }
 
+/* transfer_characteristics code -> what matrix_convert() does with it (convert.cpp:1024-1109);
+ * -1: the reference only prints a warning for every pixel */
+int tf_class(int t)
+{
+    switch (t) {
+    case 8: return H2Y_TF_LINEAR;
+    case 16: return H2Y_TF_PQ;
+    case 18: return H2Y_TF_RHO_GAMMA;
+    case 1: case 6: case 14: case 15: return H2Y_TF_BT1886; /* BT709, BT601, BT2020_10bit, BT2020_12bit */
+    default: return -1;
+    }
+}
+
 int in_kind_of(const h2y_desc *d)
 {
     return d->in_sample_type == H2Y_SAMPLE_F32 ? H2Y_IN_F32 : d->in_sample_type == H2Y_SAMPLE_F16 ? H2Y_IN_F16 : H2Y_IN_U16;
@@ -153,7 +166,10 @@ void derive_params(const h2y_desc *d, pix_params *pp, bool stage_matrix_only)
     const int tmp_depth = tmp_depth_of(d);
     const clip_limits tc = make_clip(tmp_depth, d->dst_full_range);
     const clip_limits oc = make_clip(d->dst_bit_depth, d->dst_full_range);
-    pp->convert_transfer = d->src_transfer != d->dst_transfer; /* convert.cpp:930 */
+    pp->src_tf = tf_class(d->src_transfer);
+    pp->dst_tf = tf_class(d->dst_transfer);
+    if (d->src_transfer == d->dst_transfer) pp->convert_transfer = 0; /* convert.cpp:930 */
+    else pp->convert_transfer = (pp->src_tf == H2Y_TF_LINEAR && pp->dst_tf == H2Y_TF_PQ) ? 1 : 2;
     /* convert.cpp:1123-1145 (full range: multiply only; add stays 0.0f) */
     if (d->dst_full_range) {
         pp->mulY = pp->mulC = (float)tc.maxCV;
@@ -241,6 +257,7 @@ fused_variant pick_variant(const h2y_desc *d, const pix_params &pp, int out_kind
         bool ident = known != nullptr;
         for (int c = 0; c < 3 && ident; c++) ident = known->floor_[c] == 0 && known->ceil_[c] == 1;
         v.pipe = ident ? 1 : 2; /* 2 is always valid: (x - 0) / 1 == x exactly */
+        if (pp.convert_transfer == 2) v.pipe = 0; /* generic transfer pair: runtime kernel, careful tier */
         /* half input with the identity normalisation: the whole transfer is a 64 KB table */
         if (ident && v.in_kind == H2Y_IN_F16 && (pp.mode == H2Y_MODE_YCBCR || pp.mode == H2Y_MODE_YDZDX)) v.pipe = 3;
     }
@@ -424,8 +441,12 @@ int h2y_desc_check(const h2y_desc *d, const char **why)
         if (d->chroma_resampler_type == 0 && ((d->width & 3) || (d->height & 3)))
             BAD(H2Y_EINVAL, "box resampler reads 4x4 tiles: width and height must be multiples of 4"); /* convert.cpp:100-140 */
     }
-    if (d->src_transfer != d->dst_transfer && !(d->src_transfer == H2Y_TRANSFER_LINEAR && d->dst_transfer == H2Y_TRANSFER_PQ))
-        BAD(H2Y_EUNSUPPORTED, "only LINEAR(8) -> PQ(16) or equal transfer characteristics are on this path");
+    if (d->src_transfer != d->dst_transfer) {
+        if (tf_class(d->src_transfer) < 0) BAD(H2Y_EUNSUPPORTED, "src_transfer_characteristics not supported (yet)");  /* convert.cpp:1061 */
+        if (tf_class(d->dst_transfer) < 0) BAD(H2Y_EUNSUPPORTED, "dst_transfer_characteristics not supported (yet)");  /* convert.cpp:1107 */
+        if (tf_class(d->src_transfer) == H2Y_TF_RHO_GAMMA)
+            BAD(H2Y_EUNSUPPORTED, "RHO_GAMMA as the source goes through powf(), whose libm rounding cannot be reproduced bit for bit");
+    }
     if (!(d->dst_matrix == d->src_matrix && d->dst_primaries == d->src_primaries)) {
         switch (d->dst_matrix) {
         case H2Y_MATRIX_YDZDX: case H2Y_MATRIX_BT2020NC: case H2Y_MATRIX_BT709:
@@ -760,7 +781,7 @@ int h2y_matrix_convert(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3
     var.out_kind = H2Y_OUT_444TMP;
     var.mode = pp.mode;
     var.narrow = (d->width % 4) != 0;
-    var.pipe = (pp.convert_transfer && !var.narrow) ? 2 : 0;
+    var.pipe = (pp.convert_transfer == 1 && !var.narrow) ? 2 : 0;
     const geom g = make_geom(d, H2Y_FUSED_THREADS);
     frame_io io;
     for (int c = 0; c < 3; c++) io.in[c] = d_in[c];

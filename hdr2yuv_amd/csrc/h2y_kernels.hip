@@ -156,9 +156,10 @@ __device__ __attribute__((noinline)) ycc pixel_careful(const pix_params *spp /* 
     ycc o;
     uint32_t &Y = o.y, &Cb = o.cb, &Cr = o.cr;
     if (pp.convert_transfer) {
-        G = pix_scale(pq_slow(G), pp.mulY, pp.addY);
-        B = pix_scale(pq_slow(B), pp.mulC, pp.addC);
-        R = pix_scale(pq_slow(R), pp.mulC, pp.addC);
+        /* convert.cpp:1024-1109: source transfer -> linear -> destination transfer, then the scale step */
+        G = pix_scale(tf_from_linear(pp.dst_tf, tf_to_linear(pp.src_tf, G)), pp.mulY, pp.addY);
+        B = pix_scale(tf_from_linear(pp.dst_tf, tf_to_linear(pp.src_tf, B)), pp.mulC, pp.addC);
+        R = pix_scale(tf_from_linear(pp.dst_tf, tf_to_linear(pp.src_tf, R)), pp.mulC, pp.addC);
     }
     bool dummy;
     pix_matrix<MODE, true>(pp, G, B, R, Y, Cb, Cr, &dummy);
@@ -173,7 +174,7 @@ __device__ __attribute__((noinline)) ycc pixel_careful(const pix_params *spp /* 
 /* normalisation of one sample, convert.cpp:1017-1019: binary32 subtract, IEEE divide */
 template <int PIPE> __device__ __forceinline__ float norm1(const pix_params &pp, int c, float v)
 {
-    const bool conv = PIPE == H2Y_PIPE_RUNTIME ? pp.convert_transfer : true;
+    const bool conv = PIPE == H2Y_PIPE_RUNTIME ? pp.convert_transfer != 0 : true;
     const bool ident = PIPE == H2Y_PIPE_RUNTIME ? pp.norm_identity : PIPE == H2Y_PIPE_PQ_IDENT;
     return (conv && !ident) ? (v - pp.offset[c]) / pp.range[c] : v;
 }
@@ -184,9 +185,13 @@ template <int MODE, int PIPE>
 __device__ __forceinline__ bool pixel_fast(const pix_params &pp, const pq_recA *sA, const pq_recB *sB, float G, float B, float R,
                                            uint32_t &Y, uint32_t &Cb, uint32_t &Cr)
 {
-    const bool conv = PIPE == H2Y_PIPE_RUNTIME ? pp.convert_transfer : true;
+    const bool conv = PIPE == H2Y_PIPE_RUNTIME ? pp.convert_transfer != 0 : true;
     float g = G, b = B, r = R;
     bool unsure = false;
+    if (PIPE == H2Y_PIPE_RUNTIME && pp.convert_transfer == 2) {
+        Y = Cb = Cr = 0;
+        return true; /* no fast tier for this transfer pair */
+    }
     if (conv) {
         bool sg, sb, sr;
         g = pix_scale(pq_fast(G, sA, sB, &sg), pp.mulY, pp.addY);
@@ -414,7 +419,7 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
     const pq_recB *sB = reinterpret_cast<const pq_recB *>(s_tab + H2Y_PQ_NREC);
     __shared__ float s_red[(H2Y_FUSED_THREADS / WAVE) * 6];
     __shared__ pix_params s_pp;
-    if (PIPE != H2Y_PIPE_RUNTIME || a.pp.convert_transfer) stage_table<H2Y_FUSED_THREADS>(a.table, s_tab);
+    if (PIPE != H2Y_PIPE_RUNTIME || a.pp.convert_transfer == 1) stage_table<H2Y_FUSED_THREADS>(a.table, s_tab);
     const pix_params pp = with_assumed(a.pp, a.assumed);
     if (threadIdx.x == 0) s_pp = pp;
     __syncthreads();
@@ -580,7 +585,7 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS) void k_fused_narrow(fused_args a
     const pq_recB *sB = reinterpret_cast<const pq_recB *>(s_tab + H2Y_PQ_NREC);
     __shared__ float s_red[(H2Y_FUSED_THREADS / WAVE) * 6];
     __shared__ pix_params s_pp;
-    if (a.pp.convert_transfer) stage_table<H2Y_FUSED_THREADS>(a.table, s_tab);
+    if (a.pp.convert_transfer == 1) stage_table<H2Y_FUSED_THREADS>(a.table, s_tab);
     typedef in_traits<IN_KIND> IN;
     const pix_params pp = with_assumed(a.pp, a.assumed);
     if (threadIdx.x == 0) s_pp = pp;

@@ -231,6 +231,61 @@ H2Y_FN_NOINLINE float pq_slow(float x)
     return (float)Vd;
 }
 
+/* ------------------------------------------------------------------------
+ * The other transfer functions of the same dispatch point (convert.cpp:12-87,
+ * :1024-1109), careful tier only: the reference's operations one by one with
+ * pow()/log() from the double-double routines above.  The reference is C++, so
+ * pow(float,float) there is powf and log(float) is logf (see oracle).
+ * ---------------------------------------------------------------------- */
+#define H2Y_TF_LINEAR 0
+#define H2Y_TF_PQ 1
+#define H2Y_TF_RHO_GAMMA 2
+#define H2Y_TF_BT1886 3 /* BT.709 / BT.601 / BT.2020 10- and 12-bit: gamma 2.4f, Lw 1, Lb 0 */
+
+/* pow(x, y) for any finite x >= 0 and finite y > 0 the way libm defines the edges */
+H2Y_FN double pow_gen(double x, double y)
+{
+    if (!(x >= 0.0)) return bits2d(0x7FF8000000000000ull); /* negative base, non-integer exponent: NaN */
+    if (x == 0.0) return 0.0;
+    if (x > 1.7976931348623157e308) return x; /* +inf */
+    return pow_dd(x, y);
+}
+H2Y_FN float tf_to_linear(int cls, float V)
+{
+    if (cls == H2Y_TF_PQ) { /* PQ10000_f, convert.cpp:43-51 */
+        double p = pow_gen((double)V, 1.0 / 78.84375);
+        double num = p - 0.8359375;
+        num = num > 0.0 ? num : 0.0; /* fmax(., 0.0): a NaN also gives 0.0 */
+        return (float)pow_gen(num / (18.8515625 - 18.6875 * p), 1.0 / 0.1593017578);
+    }
+    if (cls == H2Y_TF_RHO_GAMMA) { /* RHO_GAMMA_f, convert.cpp:12-27: inner pow is powf */
+        float P = (float)pow_gen(25.0, (double)V);
+        if (V < 0.0f) P = (float)(1.0 / pow_gen(25.0, -(double)V)); /* 25^V for negative V (unpinned domain) */
+        return (float)pow_gen(((double)P - 1.0) / 24.0, (double)2.4f);
+    }
+    if (cls == H2Y_TF_BT1886) { /* bt1886_f, convert.cpp:67-75, a = 1, b = 0 */
+        double v = (double)(V + 0.0f);
+        v = v > 0.0 ? v : 0.0;
+        return (float)pow_gen(v, (double)2.4f);
+    }
+    return V;
+}
+H2Y_FN float tf_from_linear(int cls, float L)
+{
+    if (cls == H2Y_TF_PQ) return pq_slow(L); /* PQ10000_r */
+    if (cls == H2Y_TF_RHO_GAMMA) {           /* RHO_GAMMA_r, convert.cpp:30-38: log(rho) is logf */
+        double a = 1.0 + 24.0 * pow_gen((double)L, 1.0 / (double)2.4f);
+        double la = (a > 0.0 && a < 1.7976931348623157e308) ? dd_log(a).hi : bits2d(0x7FF8000000000000ull);
+        return (float)(la / (double)bits2f(0x404E0210u)); /* logf(25.0f) = 3.21887589 */
+    }
+    if (cls == H2Y_TF_BT1886) { /* bt1886_r, convert.cpp:79-87 */
+        double v = (double)(L / 1.0f);
+        v = v > 0.0 ? v : 0.0;
+        return (float)(pow_gen(v, 1. / (double)2.4f) - 0.0);
+    }
+    return L;
+}
+
 /* same function in double-double throughout: the "exact" PQ the table is
  * fitted to (x > 0 given as a double-double) */
 H2Y_FN dd pq_exact_dd(dd x)
@@ -421,7 +476,9 @@ enum : int { H2Y_MODE_IDENTITY = 0, H2Y_MODE_YDZDX = 1, H2Y_MODE_YCBCR = 2, H2Y_
 
 struct pix_params {
     /* matrix_convert */
-    int convert_transfer;      /* convert.cpp:930 */
+    int convert_transfer;      /* convert.cpp:930.  0: transfers equal; 1: LINEAR -> PQ (fast tier available);
+                                  2: any other pair the reference has code for (careful tier only) */
+    int src_tf, dst_tf;        /* H2Y_TF_* classes of the two transfers */
     int norm_identity;         /* offset 0 and range 1 for all three planes */
     float offset[3], range[3]; /* convert.cpp:939-940 */
     float mulY, addY, mulC, addC; /* scale step convert.cpp:1123-1145; G: mulY/addY, B and R: mulC/addC */

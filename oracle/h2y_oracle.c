@@ -47,6 +47,59 @@ float h2y_oracle_pq10000_r(float L)
     return V;
 }
 
+/* ---- the other transfer functions at the same dispatch point, convert.cpp:12-87.
+ * The reference is C++: <math.h> there supplies float overloads, so pow(float,float)
+ * is powf and log(float) is logf, while any double argument makes the call double. */
+static float o_rho_gamma_f(float V) /* convert.cpp:12-27 */
+{
+    const float rho = 25.0f, gamma = 2.4f;
+    float P = powf(rho, V);
+    return (float)pow(((double)P - 1.0) / ((double)rho - 1.0), (double)gamma);
+}
+static float o_rho_gamma_r(float L) /* convert.cpp:30-38 */
+{
+    const float rho = 25.0f, gamma = 2.4f;
+    return (float)(log(1.0 + ((double)rho - 1.0) * pow((double)L, 1.0 / (double)gamma)) / (double)logf(rho));
+}
+static float o_pq10000_f(float V) /* convert.cpp:43-51 */
+{
+    double p = pow((double)V, 1.0 / 78.84375);
+    return (float)pow(fmax(p - 0.8359375, 0.0) / (18.8515625 - 18.6875 * p), 1.0 / 0.1593017578);
+}
+/* bt1886_f / bt1886_r, convert.cpp:67-87, as called with gamma 2.4f, Lw 1, Lb 0
+ * (convert.cpp:1052-1058, :1094-1100): a folds to 1.0f and b to 0.0f */
+static float o_bt1886_f(float V) { return (float)(1.0 * pow(fmax((double)(V + 0.0f), 0.), (double)2.4f)); }
+static float o_bt1886_r(float L) { return (float)(pow(fmax((double)(L / 1.0f), 0.), 1. / (double)2.4f) - 0.0); }
+
+static int tf_class(int t) /* 0 linear, 1 PQ, 2 rho-gamma, 3 BT.1886 family, -1 not handled */
+{
+    switch (t) {
+    case 8: return 0;
+    case 16: return 1;
+    case 18: return 2;
+    case 1: case 6: case 14: case 15: return 3; /* BT709, BT601, BT2020_10bit, BT2020_12bit: convert.cpp:1047-1050 */
+    default: return -1;
+    }
+}
+/* convert.cpp:1024-1109: source transfer -> linear -> destination transfer, one sample */
+static float o_transfer_chain(int src, int dst, float x)
+{
+    switch (tf_class(src)) {
+    case 1: x = o_pq10000_f(x); break;
+    case 2: x = o_rho_gamma_f(x); break;
+    case 3: x = o_bt1886_f(x); break;
+    default: break;
+    }
+    switch (tf_class(dst)) {
+    case 1: x = h2y_oracle_pq10000_r(x); break;
+    case 2: x = o_rho_gamma_r(x); break;
+    case 3: x = o_bt1886_r(x); break;
+    default: break;
+    }
+    return x;
+}
+float h2y_oracle_transfer_chain(int src, int dst, float x) { return o_transfer_chain(src, dst, x); }
+
 /* ---- pic_stats(), common.cpp:66-168 ------------------------------------ */
 void h2y_oracle_stats_f32(const float *const planes[3], size_t n, float mm[6],
                           int32_t floor_[3], int32_t ceil_[3])
@@ -141,10 +194,8 @@ int h2y_oracle_matrix_convert(const h2y_desc *d, const void *const in_planes[3],
     }
 
     if (convert_transfer) {
-        /* only LINEAR -> PQ is on this path; the other transfer pairs of
-         * convert.cpp:1024-1109 are SURVEY 8f row 2 */
-        if (d->src_transfer != H2Y_TRANSFER_LINEAR || d->dst_transfer != H2Y_TRANSFER_PQ)
-            return H2Y_EUNSUPPORTED;
+        /* transfers the reference has code for (convert.cpp:1024-1109); for the rest it only prints a warning per pixel */
+        if (tf_class(d->src_transfer) < 0 || tf_class(d->dst_transfer) < 0) return H2Y_EUNSUPPORTED;
     }
 
     const int identity = d->dst_matrix == d->src_matrix && d->dst_primaries == d->src_primaries; /* :1159 */
@@ -179,10 +230,10 @@ int h2y_oracle_matrix_convert(const h2y_desc *d, const void *const in_planes[3],
             G = (G - offset[0]) / range[0];
             B = (B - offset[1]) / range[1];
             R = (R - offset[2]) / range[2];
-            /* :1072-1079 */
-            G = h2y_oracle_pq10000_r(G);
-            B = h2y_oracle_pq10000_r(B);
-            R = h2y_oracle_pq10000_r(R);
+            /* :1024-1109 (LINEAR -> PQ is :1072-1079) */
+            G = o_transfer_chain(d->src_transfer, d->dst_transfer, G);
+            B = o_transfer_chain(d->src_transfer, d->dst_transfer, B);
+            R = o_transfer_chain(d->src_transfer, d->dst_transfer, R);
             /* :1123-1145 separate float multiply and float add */
             if (d->dst_full_range) {
                 G = G * maxCVf; B = B * maxCVf; R = R * maxCVf;

@@ -41,6 +41,9 @@ void h2y_oracle_set_clip(int bit_depth, int full_range, h2y_oracle_clip *clip);
 /* PQ10000_r, convert.cpp:56-63 */
 float h2y_oracle_pq10000_r(float L);
 
+/* source transfer -> linear -> destination transfer for one sample, convert.cpp:1024-1109 */
+float h2y_oracle_transfer_chain(int src_transfer, int dst_transfer, float x);
+
 /* pic_stats F32 branch, common.cpp:116-136. mm = {min0,max0,min1,max1,min2,max2} */
 void h2y_oracle_stats_f32(const float *const planes[3], size_t n, float mm[6],
                           int32_t floor_[3], int32_t ceil_[3]);

@@ -375,3 +375,24 @@ def test_caller_stream(ctx, oracle):
         fresh.set_stream(None)
     finally:
         fresh.close()
+
+
+@pytest.mark.parametrize("src,dst", [(16, 8), (8, 18), (1, 16), (8, 1), (16, 18), (6, 15), (14, 8), (8, 14), (1, 6), (15, 16)])
+def test_other_transfer_pairs(ctx, oracle, src, dst):
+    """PQ10000_f, RHO_GAMMA_r, bt1886_f/_r at the same dispatch point (careful tier)."""
+    rng = np.random.default_rng(50 + src * 19 + dst)
+    w, hh = 96, 24
+    planes = _rand_planes(rng, w, hh, h.SAMPLE_F32)
+    for (mat, depth, chroma, res) in ((h.MATRIX_BT2020NC, 12, h.CHROMA_420, 1), (h.MATRIX_YDZDX, 16, h.CHROMA_444, 0),
+                                      (h.MATRIX_BT709, 10, h.CHROMA_420, 0)):
+        d = h.make_desc(w, hh, dst_depth=depth, src_transfer=src, dst_transfer=dst, dst_matrix=mat, chroma=chroma, resampler=res)
+        got = ctx.convert_frame(d, planes)
+        want = oracle.convert_frame(_to_oracle_desc(d), planes)
+        assert np.array_equal(got, want), (mat, np.count_nonzero(got != want))
+
+
+def test_rho_gamma_source_is_refused(ctx):
+    d = h.make_desc(64, 32, src_transfer=18, dst_transfer=8)
+    with pytest.raises(h.H2YError) as e:
+        ctx.convert_frame(d, [np.zeros(64 * 32, np.float32)] * 3)
+    assert e.value.code == 2

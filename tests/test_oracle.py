@@ -116,3 +116,18 @@ def test_pq_equals_reference(oracle, ref):
     xs = np.concatenate([rng.uniform(0, 1, 4000), 2.0 ** rng.uniform(-40, 1, 4000), [0.0, 1.0, 2.0, 1e-30]]).astype(np.float32)
     for x in xs:
         assert np.float32(oracle.pq(float(x))).view(np.uint32) == np.float32(ref.pq(float(x))).view(np.uint32)
+
+
+def test_other_transfer_pairs_equal_reference(oracle, ref):
+    """every source/destination transfer pair the reference has code for
+    (convert.cpp:1024-1109), including RHO_GAMMA in both directions."""
+    rng = np.random.default_rng(12)
+    w, h = 48, 16
+    pairs = [(16, 8), (8, 18), (18, 8), (1, 16), (8, 1), (16, 18), (18, 16), (6, 15), (14, 8), (8, 14), (1, 6), (18, 1), (15, 16)]
+    for (src, dst) in pairs:
+        planes = [rng.uniform(0, 1, w * h).astype(np.float32) for _ in range(3)]
+        for p in planes:
+            p[0], p[1] = 0.0, 1.0
+        for (mat, dep, ch, res) in ((ob.MATRIX_BT2020NC, 12, 1, 1), (ob.MATRIX_YDZDX, 16, 3, 0)):
+            d = ob.make_desc(w, h, dst_depth=dep, src_transfer=src, dst_transfer=dst, dst_matrix=mat, chroma=ch, resampler=res)
+            assert np.array_equal(oracle.convert_frame(d, planes), ref.convert_frame(d, planes)), (src, dst, mat)

@@ -62,6 +62,32 @@ int main(int argc, char **argv)
                100.0 * bad1 / n, bad2, 100.0 * bad2 / n, big);
         return 0;
     }
+    if (!strcmp(argv[1], "tf")) {
+        /* the other transfer functions (careful tier only) against libm, random inputs in [0, 1.25) */
+        long n = argc > 2 ? atol(argv[2]) : 2000000;
+        std::mt19937_64 rng(7);
+        long bad[6] = {0, 0, 0, 0, 0, 0};
+        for (long i = 0; i < n; i++) {
+            float x = (float)(rng() >> 40) * (1.25f / 16777216.0f);
+            if (i < 4) x = i == 0 ? 0.0f : i == 1 ? 1.0f : i == 2 ? 0x1p-30f : 1.2f;
+            /* reference formulas, convert.cpp:12-87 with C++ overload resolution */
+            float r_pqf = (float)pow(fmax(pow((double)x, 1.0 / 78.84375) - 0.8359375, 0.0) / (18.8515625 - 18.6875 * pow((double)x, 1.0 / 78.84375)), 1.0 / 0.1593017578);
+            float r_rgf = (float)pow(((double)powf(25.0f, x) - 1.0) / (25.0 - 1.0), (double)2.4f);
+            float r_rgr = (float)(log(1.0 + (25.0 - 1.0) * pow((double)x, 1.0 / (double)2.4f)) / (double)logf(25.0f));
+            float r_btf = (float)(1.0 * pow(fmax((double)(x + 0.0f), 0.), (double)2.4f));
+            float r_btr = (float)(pow(fmax((double)(x / 1.0f), 0.), 1. / (double)2.4f) - 0.0);
+            float g[5] = {tf_to_linear(H2Y_TF_PQ, x), tf_to_linear(H2Y_TF_RHO_GAMMA, x), tf_from_linear(H2Y_TF_RHO_GAMMA, x),
+                          tf_to_linear(H2Y_TF_BT1886, x), tf_from_linear(H2Y_TF_BT1886, x)};
+            float w[5] = {r_pqf, r_rgf, r_rgr, r_btf, r_btr};
+            for (int k = 0; k < 5; k++)
+                if (f2bits(g[k]) != f2bits(w[k]) && !(g[k] != g[k] && w[k] != w[k])) {
+                    if (bad[k]++ < 2) fprintf(stderr, "tf mismatch fn %d x=%a got %a want %a\n", k, x, g[k], w[k]);
+                }
+        }
+        printf("transfer functions vs libm over %ld inputs: PQ_f %ld, RHO_f %ld, RHO_r %ld, BT1886_f %ld, BT1886_r %ld mismatches\n", n, bad[0], bad[1],
+               bad[2], bad[3], bad[4]);
+        return (bad[0] | bad[2] | bad[3] | bad[4]) ? 1 : 0; /* RHO_f goes through powf, which libm does not round correctly every time */
+    }
     if (!strcmp(argv[1], "approx")) {
         /* binary32 screening polynomial: max |approx - reference double| / value over [LO,HI) */
         uint32_t lo = (uint32_t)strtoul(argv[2], 0, 0), hi = (uint32_t)strtoul(argv[3], 0, 0);

@@ -66,6 +66,7 @@ struct h2y_ctx {
     hipEvent_t ev_fused[2] = {nullptr, nullptr}, ev_fir[2] = {nullptr, nullptr};
     bool fir_used[2] = {false, false};
     void *d_table = nullptr;
+    void *d_table1 = nullptr; /* binary32 first-tier records */
     float *d_lut16 = nullptr; /* PQ10000_r of every half in [0,2), built on the device at creation */
     /* per-batch device arrays */
     frame_io *d_frames = nullptr, *h_frames = nullptr;
@@ -245,8 +246,20 @@ int grid_for(const h2y_ctx *ctx, const fused_variant &v, uint64_t total_chunks)
 
 /* known: the floor/ceiling the kernels will assume, when the HOST knows them (hint or
  * override); NULL when they only exist in device memory (stats pre-pass). */
-fused_variant pick_variant(const h2y_desc *d, const pix_params &pp, int out_kind, const assumed_stats *known)
+/* H2Y_T1=0 in the environment keeps the binary32 first tier off (A/B timing) */
+bool t1_enabled()
 {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("H2Y_T1");
+        v = (e && e[0] == '0') ? 0 : 1;
+    }
+    return v == 1;
+}
+
+fused_variant pick_variant(const h2y_desc *d, const pix_params &pp, int out_kind, const assumed_stats *known, t1_sens *sn)
+{
+    memset(sn, 0, sizeof *sn);
     fused_variant v;
     v.in_kind = in_kind_of(d);
     v.out_kind = out_kind;
@@ -258,6 +271,8 @@ fused_variant pick_variant(const h2y_desc *d, const pix_params &pp, int out_kind
         for (int c = 0; c < 3 && ident; c++) ident = known->floor_[c] == 0 && known->ceil_[c] == 1;
         v.pipe = ident ? 1 : 2; /* 2 is always valid: (x - 0) / 1 == x exactly */
         if (pp.convert_transfer == 2) v.pipe = 0; /* generic transfer pair: runtime kernel, careful tier */
+        /* binary32 first tier where few pixels would fall through it (moderate bit depths) */
+        if ((v.pipe == 1 || v.pipe == 2) && v.in_kind != H2Y_IN_U16 && t1_enabled() && t1_bounds(pp, sn)) v.pipe += 3;
         /* half input with the identity normalisation: the whole transfer is a 64 KB table */
         if (ident && v.in_kind == H2Y_IN_F16 && (pp.mode == H2Y_MODE_YCBCR || pp.mode == H2Y_MODE_YDZDX)) v.pipe = 3;
     }
@@ -277,8 +292,9 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
     pix_params pp;
     derive_params(d, &pp, false);
     const int out_kind = out_kind_of(d);
-    const fused_variant var = pick_variant(d, pp, out_kind, known);
-    const geom g = make_geom(d, H2Y_FUSED_THREADS);
+    t1_sens sn;
+    const fused_variant var = pick_variant(d, pp, out_kind, known, &sn);
+    const geom g = make_geom(d, h2y_fused_threads(var));
     const size_t npix = (size_t)d->width * d->height;
     const int step = out_kind == H2Y_OUT_444TMP ? kFirSubBatch : n;
     if (out_kind == H2Y_OUT_444TMP) {
@@ -317,6 +333,8 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         a.chunks_per_frame = g.chunks;
         a.table = ctx->d_table;
         a.lut16 = ctx->d_lut16;
+        a.table1 = ctx->d_table1;
+        a.sn = sn;
         a.partial = ctx->d_partial;
         a.assumed = d_assumed;
         a.pp = pp;
@@ -517,6 +535,10 @@ int h2y_ctx_create(int device, h2y_ctx **out)
         ctx->d_table = t;
         HIP_TRY(ctx, hipMemcpy(t, A.data(), H2Y_PQ_NREC * 16, hipMemcpyHostToDevice));
         HIP_TRY(ctx, hipMemcpy(t + H2Y_PQ_NREC * 16, B.data(), H2Y_PQ_NREC * 16, hipMemcpyHostToDevice));
+        std::vector<pq_rec1> T1(H2Y_T1_NREC);
+        pq_build_table1(T1.data());
+        HIP_TRY(ctx, hipMalloc(&ctx->d_table1, H2Y_T1_NREC * sizeof(pq_rec1)));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_table1, T1.data(), H2Y_T1_NREC * sizeof(pq_rec1), hipMemcpyHostToDevice));
         HIP_TRY(ctx, hipMalloc((void **)&ctx->d_lut16, H2Y_LUT16_N * sizeof(float)));
         HIP_TRY(ctx, h2y_launch_build_lut16(ctx->stream, ctx->d_table, ctx->d_lut16));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -540,6 +562,7 @@ void h2y_ctx_destroy(h2y_ctx *ctx)
     }
     (void)hipFree(ctx->d_table);
     (void)hipFree(ctx->d_lut16);
+    (void)hipFree(ctx->d_table1);
     (void)hipFree(ctx->d_frames);
     (void)hipHostFree(ctx->h_frames);
     (void)hipFree(ctx->d_partial);
@@ -804,6 +827,8 @@ int h2y_matrix_convert(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3
     a.chunks_per_frame = g.chunks;
     a.table = ctx->d_table;
     a.lut16 = ctx->d_lut16;
+    a.table1 = ctx->d_table1;
+    memset(&a.sn, 0, sizeof a.sn);
     a.partial = ctx->d_partial;
     a.assumed = ctx->d_assumed;
     a.pp = pp;

@@ -55,6 +55,8 @@ struct fused_args {
     uint32_t chunks_per_frame;
     const void *table;        /* pq_recA[NREC] then pq_recB[NREC] */
     const float *lut16;       /* k_fused_lut16: PQ of every half in [0,2) */
+    const void *table1;       /* k_fused_t1: pq_rec1[H2Y_T1_NREC] */
+    h2y::t1_sens sn;          /* k_fused_t1: sensitivity windows */
     float *partial;           /* [n_frames][grid][6] */
     const assumed_stats *assumed;
     h2y::pix_params pp;       /* offset/range/norm_identity are filled in-kernel from *assumed */
@@ -64,7 +66,8 @@ struct fused_args {
 struct fused_variant {
     int in_kind, out_kind, mode;
     int pipe;      /* 0 runtime flags, 1 LINEAR->PQ with floor 0/ceiling 1, 2 LINEAR->PQ general normalisation,
-                      3 as 1 for half input through the 16 384-entry table (k_fused_lut16) */
+                      3 as 1 for half input through the 16 384-entry table (k_fused_lut16),
+                      4 / 5 as 1 / 2 with the binary32 first tier in front (k_fused_t1) */
     bool narrow;   /* width % 4 != 0: scalar-load variant */
 };
 
@@ -96,6 +99,7 @@ struct fir_args {
     h2y::pix_params pp;
 };
 
+int h2y_fused_threads(const fused_variant &v);
 int h2y_fused_blocks_per_cu(const fused_variant &v);
 hipError_t h2y_launch_fused(const fused_variant &v, int grid, hipStream_t st, const fused_args &a);
 hipError_t h2y_launch_build_lut16(hipStream_t st, const void *table, float *lut);

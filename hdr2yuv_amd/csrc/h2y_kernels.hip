@@ -453,6 +453,105 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
 }
 
 /*
+ * k_fused_t1: the same work with a binary32 FIRST TIER in front (PQ output,
+ * YCbCr or YDzDx, bit depths where t1_bounds() says it pays).
+ *
+ *   tier 1  pq_t1(): one 16-byte LDS record and ~16 binary32 instructions per
+ *           sample give the reference's float for 99.3 % of samples and say so;
+ *           the matrix step is the exact one (pix_matrix_t1).  A pixel is final
+ *           unless one of its samples was "unsure" AND one of its three integers
+ *           could change with a one-ulp change of that sample (0.05 % of pixels
+ *           at 12 bits), or the reciprocal-division guard fires.
+ *   tier 2  such pixels go through pixel_fast<>() -- the binary64 polynomial --
+ *           with its table read straight from HBM/L2 (rare, so no LDS copy),
+ *   tier 3  and from there, as before, to pixel_careful().
+ *
+ * 1024 threads per block, one block per CU: the T1 table (256 segments per
+ * binade) takes 100 KB of LDS.
+ */
+#define H2Y_T1_THREADS 1024
+/* tiers 2 and 3 for one pixel, out of line: parameters come from the block's LDS copy and
+ * the binary64 table from HBM/L2, so the hot loop carries none of their registers */
+template <int MODE>
+__device__ __attribute__((noinline)) ycc pixel_t23(const pix_params *spp, const void *table, float G, float B, float R)
+{
+    const pix_params &pp = *spp;
+    const pq_recA *gA = static_cast<const pq_recA *>(table);
+    const pq_recB *gB = reinterpret_cast<const pq_recB *>(gA + H2Y_PQ_NREC);
+    ycc o;
+    if (pixel_fast<MODE, H2Y_PIPE_PQ_IDENT>(pp, gA, gB, G, B, R, o.y, o.cb, o.cr)) return pixel_careful<MODE>(spp, G, B, R);
+    return o;
+}
+template <int MODE>
+__device__ __forceinline__ void pixel_t1(const pix_params &pp, const t1_sens &sn, const pix_params *spp, const pq_rec1 *sT1,
+                                         const void *table, float G, float B, float R, uint32_t &Y, uint32_t &Cb, uint32_t &Cr)
+{
+    bool ug, ub, ur;
+    const float g = pix_scale(pq_t1(G, sT1, &ug), pp.mulY, pp.addY);
+    const float b = pix_scale(pq_t1(B, sT1, &ub), pp.mulC, pp.addC);
+    const float r = pix_scale(pq_t1(R, sT1, &ur), pp.mulC, pp.addC);
+    if (__builtin_expect(pix_matrix_t1<MODE>(pp, sn, g, b, r, ug | ub | ur, Y, Cb, Cr), 0)) {
+        const ycc c = pixel_t23<MODE>(spp, table, G, B, R);
+        Y = c.y; Cb = c.cb; Cr = c.cr;
+    }
+}
+
+template <int IN_KIND, int OUT_KIND, int MODE, int PIPE>
+__global__ __launch_bounds__(H2Y_T1_THREADS, 4) void k_fused_t1(fused_args a)
+{
+    __shared__ pq_rec1 s_t1[H2Y_T1_NREC];
+    __shared__ float s_red[(H2Y_T1_THREADS / WAVE) * 6];
+    __shared__ pix_params s_pp;
+    {
+        const uint4 *g = reinterpret_cast<const uint4 *>(a.table1);
+        uint4 *l = reinterpret_cast<uint4 *>(s_t1);
+        for (int i = threadIdx.x; i < H2Y_T1_NREC; i += H2Y_T1_THREADS) l[i] = g[i];
+    }
+    const pix_params pp = with_assumed(a.pp, a.assumed);
+    const t1_sens sn = a.sn;
+    if (threadIdx.x == 0) s_pp = pp;
+    __syncthreads();
+
+    const uint32_t W = a.width, H = a.height, G = gridDim.x;
+    for (int f = 0; f < a.n_frames; f++) {
+        const frame_io io = a.frames[f];
+        mm6 mm;
+        mm.reset();
+        const uint32_t gbase = (uint32_t)(((uint64_t)f * a.chunks_per_frame) % G);
+        uint32_t k = (blockIdx.x + G - gbase) % G;
+        for (; k < a.chunks_per_frame; k += G) {
+            const uint32_t tt = k * H2Y_T1_THREADS + threadIdx.x;
+            if (tt >= a.tiles_per_frame) continue;
+            const tile_pos t = tile_locate(tt, W, H, a.wq, a.wq_magic);
+            tile_in v;
+            tile_load<IN_KIND>(io, t, v);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                mm.add2(0, v.g0[j], v.g1[j]);
+                mm.add2(1, v.b0[j], v.b1[j]);
+                mm.add2(2, v.r0[j], v.r1[j]);
+            }
+            tile_out o;
+#pragma unroll
+            for (int jb = 0; jb < 2; jb++) {
+                uint32_t Y[4], Cb[4], Cr[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const int col = 2 * jb + (q & 1);
+                    const float Gn = norm1<PIPE>(pp, 0, q < 2 ? v.g0[col] : v.g1[col]);
+                    const float Bn = norm1<PIPE>(pp, 1, q < 2 ? v.b0[col] : v.b1[col]);
+                    const float Rn = norm1<PIPE>(pp, 2, q < 2 ? v.r0[col] : v.r1[col]);
+                    pixel_t1<MODE>(pp, sn, &s_pp, s_t1, a.table, Gn, Bn, Rn, Y[q], Cb[q], Cr[q]);
+                }
+                tile_pack<OUT_KIND>(pp, jb, Y, Cb, Cr, o);
+            }
+            tile_store<OUT_KIND>(io, t, W, H, o);
+        }
+        block_store_mm<H2Y_T1_THREADS / WAVE>(mm, s_red, a.partial + ((size_t)f * G + blockIdx.x) * 6);
+    }
+}
+
+/*
  * k_fused_lut16: half-float input (EXR, exr.cpp:233), LINEAR -> PQ, floor 0 /
  * ceiling 1.  A half in [0, 2) has only 16 384 bit patterns, so PQ10000_r() of
  * every one of them fits in LDS (64 KB of binary32, built once per context by
@@ -862,8 +961,26 @@ template <int OUT_KIND> static fused_fn pick_lut_mode(int mode)
 {
     return mode == H2Y_MODE_YCBCR ? k_fused_lut16<OUT_KIND, H2Y_MODE_YCBCR> : k_fused_lut16<OUT_KIND, H2Y_MODE_YDZDX>;
 }
+template <int IN_KIND, int OUT_KIND> static fused_fn pick_t1_mode(int mode, int pipe)
+{
+    if (mode == H2Y_MODE_YCBCR)
+        return pipe == 4 ? k_fused_t1<IN_KIND, OUT_KIND, H2Y_MODE_YCBCR, H2Y_PIPE_PQ_IDENT> : k_fused_t1<IN_KIND, OUT_KIND, H2Y_MODE_YCBCR, H2Y_PIPE_PQ_NORM>;
+    return pipe == 4 ? k_fused_t1<IN_KIND, OUT_KIND, H2Y_MODE_YDZDX, H2Y_PIPE_PQ_IDENT> : k_fused_t1<IN_KIND, OUT_KIND, H2Y_MODE_YDZDX, H2Y_PIPE_PQ_NORM>;
+}
+template <int IN_KIND> static fused_fn pick_t1_out(int out_kind, int mode, int pipe)
+{
+    switch (out_kind) {
+    case H2Y_OUT_420BOX: return pick_t1_mode<IN_KIND, H2Y_OUT_420BOX>(mode, pipe);
+    case H2Y_OUT_444: return pick_t1_mode<IN_KIND, H2Y_OUT_444>(mode, pipe);
+    default: return pick_t1_mode<IN_KIND, H2Y_OUT_444TMP>(mode, pipe);
+    }
+}
+int h2y_fused_threads(const fused_variant &v) { return (v.pipe == 4 || v.pipe == 5) ? H2Y_T1_THREADS : H2Y_FUSED_THREADS; }
+
 static fused_fn pick_fused(const fused_variant &v)
 {
+    if (v.pipe == 4 || v.pipe == 5) /* first-tier kernels: float inputs only */
+        return v.in_kind == H2Y_IN_F16 ? pick_t1_out<H2Y_IN_F16>(v.out_kind, v.mode, v.pipe) : pick_t1_out<H2Y_IN_F32>(v.out_kind, v.mode, v.pipe);
     if (v.pipe == 3) {
         switch (v.out_kind) {
         case H2Y_OUT_420BOX: return pick_lut_mode<H2Y_OUT_420BOX>(v.mode);
@@ -883,7 +1000,7 @@ int h2y_fused_blocks_per_cu(const fused_variant &v)
 {
     int nb = 0;
     fused_fn fn = pick_fused(v);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(fn), H2Y_FUSED_THREADS, 0) != hipSuccess || nb < 1)
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void *>(fn), h2y_fused_threads(v), 0) != hipSuccess || nb < 1)
         nb = 1;
     return nb;
 }
@@ -891,7 +1008,7 @@ int h2y_fused_blocks_per_cu(const fused_variant &v)
 hipError_t h2y_launch_fused(const fused_variant &v, int grid, hipStream_t st, const fused_args &a)
 {
     fused_fn fn = pick_fused(v);
-    hipLaunchKernelGGL(fn, dim3(grid), dim3(H2Y_FUSED_THREADS), 0, st, a);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(h2y_fused_threads(v)), 0, st, a);
     return hipGetLastError();
 }
 

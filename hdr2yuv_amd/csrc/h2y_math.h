@@ -223,7 +223,8 @@ H2Y_FN double pow_dd(double x, double y) { return dd_exp(dd_mul_d(dd_log(x), y))
 H2Y_FN_NOINLINE float pq_slow(float x)
 {
     if (!(x >= 0.0f) || x > 3.4028234e38f) return bits2f(0x7FC00000u);
-    double Ln = (x == 0.0f) ? 0.0 : pow_dd((double)x, H2Y_PQ_M1);
+    if (x == 0.0f) return bits2f(H2Y_PQ_AT_ZERO_BITS); /* black is common: pow(0, m1) = 0, so this is a constant */
+    double Ln = pow_dd((double)x, H2Y_PQ_M1);
     double num = H2Y_PQ_C1 + H2Y_PQ_C2 * Ln;
     double den = 1.0 + H2Y_PQ_C3 * Ln;
     double B = num / den;
@@ -470,6 +471,87 @@ inline void pq_build_table(pq_recA *A, pq_recB *B)
 }
 
 /* ------------------------------------------------------------------------
+ * First tier ("T1"): binary32 only, one 16-byte record per sample.
+ *
+ * value = c0h + w,  w = c0l + u (c1 + u c2)   (all binary32; u exact)
+ * over 256 segments per binade (exponent + top 8 mantissa bits; 6401 records,
+ * 100 KB).  c0h + c0l is the segment's constant term split in two floats, so the
+ * only rounding that matters is the one of w (|w| <= 2^-9.5 of the value): the REAL number
+ * c0h + w is within H2Y_T1_RELERR of the reference's double value.  The float
+ * s = RN(c0h + w) is therefore the reference's float unless c0h + w lies
+ * within that distance of a rounding tie; e = w - (s - c0h) is the exact
+ * rounding error of the addition, so the test is |e| >= ulp(s)/2 - delta.
+ * About 0.7 % of samples fail it (*unsure); their pixel is redone by the
+ * binary64 tier only when its integers are sensitive to a one-ulp change of
+ * V (pixel_t1 in the kernels).  Checked exhaustively: every float of the
+ * domain that passes the test gives the reference's float (tools/pq_check t1).
+ * ---------------------------------------------------------------------- */
+#define H2Y_T1_SEG_BITS 8
+#define H2Y_T1_LOW_BITS (23 - H2Y_T1_SEG_BITS)
+#define H2Y_T1_NSEG (H2Y_PQ_NBINADES << H2Y_T1_SEG_BITS)
+#define H2Y_T1_NREC (H2Y_T1_NSEG + 1)
+#define H2Y_T1_BASE ((uint32_t)(127 + H2Y_PQ_EMIN) << H2Y_T1_SEG_BITS)
+#define H2Y_T1_RELERR 2.9e-10f /* measured max 2.523e-10 over every float of the domain (tools/pq_check t1), +15 % */
+struct alignas(16) pq_rec1 {
+    float c0h, c0l, c1, c2;
+};
+/* the real-number value of the T1 evaluation, as (c0h, w); shared with tools */
+H2Y_FN void pq_t1_parts(uint32_t bits, const pq_rec1 &r, float *c0h, float *w)
+{
+    float f = bits2f((bits & ((1u << H2Y_T1_LOW_BITS) - 1u)) | 0x3F800000u);
+    float u = f - (1.0f + 1.0f / (float)(2 << H2Y_T1_SEG_BITS));
+    *w = __builtin_fmaf(__builtin_fmaf(r.c2, u, r.c1), u, r.c0l);
+    *c0h = r.c0h;
+}
+H2Y_FN uint32_t pq_t1_offset(uint32_t bits)
+{
+    uint32_t t = bits - (H2Y_T1_BASE << H2Y_T1_LOW_BITS);
+    return umin32(t >> H2Y_T1_LOW_BITS, (uint32_t)H2Y_T1_NSEG) << 4;
+}
+H2Y_FN float pq_t1(float x, const pq_rec1 *__restrict__ T, bool *unsure)
+{
+    const uint32_t bits = f2bits(x);
+    const pq_rec1 r = *reinterpret_cast<const pq_rec1 *>(reinterpret_cast<const char *>(T) + pq_t1_offset(bits));
+    float c0h, w;
+    pq_t1_parts(bits, r, &c0h, &w);
+    const float s = c0h + w;
+    const float e = w - (s - c0h);                                          /* exact: |c0h| >= |w| */
+    const float half_ulp = bits2f((f2bits(s) & 0x7F800000u) - (24u << 23)); /* 2^(E-24) */
+    const float thr = __builtin_fmaf(s, -H2Y_T1_RELERR, half_ulp);
+    *unsure = !(__builtin_fabsf(e) < thr); /* NaN (sentinel record) => unsure */
+    return s;
+}
+inline void pq_build_table1(pq_rec1 *T)
+{
+    const double wn[3] = {-0.8660254037844386, 0.0, 0.8660254037844386};
+    for (int i = 0; i < H2Y_T1_NSEG; i++) {
+        int e = H2Y_PQ_EMIN + (i >> H2Y_T1_SEG_BITS);
+        int sg = i & ((1 << H2Y_T1_SEG_BITS) - 1);
+        double scale = bits2d((uint64_t)(1023 + e) << 52);
+        double mid = scale * (1.0 + (sg + 0.5) / (1 << H2Y_T1_SEG_BITS));
+        double half = scale * (0.5 / (1 << H2Y_T1_SEG_BITS));
+        dd ev[3];
+        for (int j = 0; j < 3; j++) ev[j] = pq_exact_dd(dd_add_d(two_prod(wn[j], half), mid));
+        for (int lvl = 1; lvl < 3; lvl++)
+            for (int j = 2; j >= lvl; j--) {
+                dd num = dd_add(ev[j], dd{-ev[j - 1].hi, -ev[j - 1].lo});
+                ev[j] = dd_div(num, dd{wn[j] - wn[j - lvl], 0.0});
+            }
+        /* p(w) = ev0 + (w-w0) ev1 + (w-w0)(w-w1) ev2, with (w-w0)(w-w1) = w^2 - (w0+w1) w + w0 w1 */
+        const dd q2 = ev[2];
+        const dd q1 = dd_add(ev[1], dd_mul_d(q2, -(wn[0] + wn[1])));
+        const dd q0 = dd_add(dd_add(ev[0], dd_mul_d(ev[1], -wn[0])), dd_mul_d(q2, wn[0] * wn[1]));
+        const double r = (double)(2 << H2Y_T1_SEG_BITS);
+        T[i].c0h = (float)q0.hi;
+        T[i].c0l = (float)((q0.hi - (double)T[i].c0h) + q0.lo);
+        T[i].c1 = (float)(q1.hi * r);
+        T[i].c2 = (float)(q2.hi * r * r);
+    }
+    T[H2Y_T1_NSEG].c0h = bits2f(0x7FC00000u);
+    T[H2Y_T1_NSEG].c0l = T[H2Y_T1_NSEG].c1 = T[H2Y_T1_NSEG].c2 = 0.0f;
+}
+
+/* ------------------------------------------------------------------------
  * Per-frame constants handed to the kernels.
  * ---------------------------------------------------------------------- */
 enum : int { H2Y_MODE_IDENTITY = 0, H2Y_MODE_YDZDX = 1, H2Y_MODE_YCBCR = 2, H2Y_MODE_YPQRS = 3 };
@@ -524,6 +606,16 @@ H2Y_FN int32_t sat_i32_f64(double v)
     if (v >= 2147483648.0) return 2147483647;
     if (v <= -2147483648.0) return (int32_t)0x80000000;
     return (int32_t)v;
+#endif
+}
+/* x - floor(x) in [0,1) (v_fract_f32) */
+H2Y_FN float fract_f32(float v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fractf(v);
+#else
+    float fr = v - __builtin_floorf(v);
+    return fr >= 1.0f ? 0x1.fffffep-1f : fr;
 #endif
 }
 /* x - floor(x), in [0,1) (v_fract_f64) */
@@ -617,6 +709,84 @@ H2Y_FN void pix_matrix(const pix_params &pp, float G, float B, float R, uint32_t
     }
     Cbo = chroma_clamped(cb, pp.half_m1, pp.maxCV);
     Cro = chroma_clamped(cr, pp.half_m1, pp.maxCV);
+}
+
+/* ---- first-tier (T1) form of the matrix step ------------------------------
+ * Same arithmetic as pix_matrix<MODE,false>.  When one of the pixel's three PQ
+ * values came out of pq_t1() "unsure" (it may be one float ulp off), the
+ * integers are accepted only if none of the three pre-truncation values is
+ * close enough to an integer for such a change to matter (bounds: t1_bounds()).
+ * Returns true when the pixel must be redone by the binary64 tier. */
+struct t1_sens {
+    float ty;                 /* luma safe iff |fract(y) - 0.5| < ty                     */
+    uint32_t cb_lo, cb_span;  /* chroma unsafe iff (hiword(fract(q)) - lo) >= span (wide) */
+    uint32_t cr_lo, cr_span;
+};
+#define H2Y_GUARD_LO 0x3E100000u                  /* hiword(2^-30): the always-on guard of the reciprocal division */
+#define H2Y_GUARD_SPAN (0x3FEFFFFFu - 0x3E100000u) /* up to hiword(1 - 2^-21) */
+
+template <int MODE>
+H2Y_FN bool pix_matrix_t1(const pix_params &pp, const t1_sens &sn, float G, float B, float R, bool vunc, uint32_t &Yo,
+                          uint32_t &Cbo, uint32_t &Cro)
+{
+    float ylike;
+    double qb, qr;
+    if (MODE == H2Y_MODE_YCBCR) {
+        double yd = ((pp.kr * (double)R + pp.kg * (double)G) + pp.kb * (double)B) + 0.5;
+        float tmpF = (float)yd;
+        ylike = tmpF;
+        qb = __builtin_fma((double)(B - tmpF), pp.inv_dcb, 0.5);
+        qr = __builtin_fma((double)(R - tmpF), pp.inv_dcr, 0.5);
+    } else { /* H2Y_MODE_YDZDX */
+        ylike = G;
+        double hg = (double)(-G) * 0.5;
+        qb = (hg + (double)B * 0.5) + 0.5;
+        qr = (hg + (double)R * 0.5) + 0.5;
+    }
+    Yo = f2u_clamped(ylike, pp.maxCV);
+    Cbo = chroma_clamped(sat_i32_f64(qb), pp.half_m1, pp.maxCV);
+    Cro = chroma_clamped(sat_i32_f64(qr), pp.half_m1, pp.maxCV);
+    const uint32_t fb = (uint32_t)(d2bits(fract_f64(qb)) >> 32), fr = (uint32_t)(d2bits(fract_f64(qr)) >> 32);
+    const bool y_unsafe = !(__builtin_fabsf(fract_f32(ylike) - 0.5f) < sn.ty); /* NaN => unsafe */
+    const bool cb_unsafe = (fb - (vunc ? sn.cb_lo : H2Y_GUARD_LO)) >= (vunc ? sn.cb_span : H2Y_GUARD_SPAN);
+    const bool cr_unsafe = (fr - (vunc ? sn.cr_lo : H2Y_GUARD_LO)) >= (vunc ? sn.cr_span : H2Y_GUARD_SPAN);
+    /* YDzDx has no division, so without an unsure sample its chroma needs no guard at all */
+    const bool guard = MODE == H2Y_MODE_YCBCR ? (cb_unsafe | cr_unsafe) : (vunc & (cb_unsafe | cr_unsafe));
+    return guard | (vunc & y_unsafe);
+}
+
+/* Host: how far a one-ulp change of each PQ value can move the pre-truncation
+ * values (u23 = 2^-23 bounds one ulp relative to the magnitude):
+ *   s = RN(RN(V mul) + add): the product moves by mul ulp(V) and may round one
+ *       ulp further, the sum may round one ulp further: <= 3 u23 smax
+ *   y (YCbCr): sum of the three weighted by k (sum 1), + one ulp of tmpF
+ *   d = RN(s - tmpF): both moves + one ulp; q = d / c
+ * 10 % slack on top.  Returns false when the windows get so wide that most
+ * pixels with an unsure sample would be redone anyway (high bit depths). */
+H2Y_FN uint32_t hiword_of(double v) { return (uint32_t)(d2bits(v) >> 32); }
+inline bool t1_bounds(const pix_params &pp, t1_sens *sn)
+{
+    const double u23 = 0x1p-23;
+    const double sY = (double)pp.mulY * 1.2 + pp.addY, sC = (double)pp.mulC * 1.2 + pp.addC; /* PQ < 1.2 on the table's domain */
+    const double smax = sY > sC ? sY : sC;
+    double Ey, Ecb, Ecr;
+    if (pp.mode == H2Y_MODE_YCBCR) {
+        const double ymax = smax + 0.5;
+        Ey = (3 * u23 * smax + u23 * ymax) * 1.1;
+        const double Ed = (3 * u23 * smax + 4 * u23 * ymax + u23 * ymax) * 1.1;
+        Ecb = Ed / pp.dcb;
+        Ecr = Ed / pp.dcr;
+    } else if (pp.mode == H2Y_MODE_YDZDX) {
+        Ey = 3 * u23 * sY * 1.1;
+        Ecb = Ecr = (3 * u23 * sY + 3 * u23 * sC) * 0.5 * 1.1;
+    } else return false;
+    sn->ty = (float)(0.5 - Ey);
+    sn->cb_lo = hiword_of(Ecb) + 1;
+    sn->cb_span = hiword_of(1.0 - Ecb) - sn->cb_lo;
+    sn->cr_lo = hiword_of(Ecr) + 1;
+    sn->cr_span = hiword_of(1.0 - Ecr) - sn->cr_lo;
+    /* ~10 % of pixels have an unsure sample; redo rate ~ 0.1 * 2 (Ey + Ecb + Ecr) must stay small */
+    return (Ey + Ecb + Ecr) < 0.02;
 }
 
 /* scale step, convert.cpp:1123-1145: separate multiply and add in binary32.

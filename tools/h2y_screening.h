@@ -58,16 +58,6 @@ struct approx_params {
     float ty, tcb, tcr;     /* 0.5 - E: "certain" iff |fract(v) - 0.5| < t */
 };
 
-/* fract(v) = v - floor(v) in [0,1) (v_fract_f32) */
-H2Y_FN float fract_f32(float v)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_fractf(v);
-#else
-    float fr = v - __builtin_floorf(v);
-    return fr >= 1.0f ? 0x1.fffffep-1f : fr;
-#endif
-}
 /* NaN-safe: a NaN v gives false */
 H2Y_FN bool far_from_integer(float v, float t) { return __builtin_fabsf(fract_f32(v) - 0.5f) < t; }
 

@@ -62,6 +62,45 @@ int main(int argc, char **argv)
                100.0 * bad1 / n, bad2, 100.0 * bad2 / n, big);
         return 0;
     }
+    if (!strcmp(argv[1], "t1")) {
+        /* first tier: every float in [LO,HI): unflagged results must equal the reference float */
+        uint32_t lo = (uint32_t)strtoul(argv[2], 0, 0), hi = (uint32_t)strtoul(argv[3], 0, 0);
+        int T = argc > 4 ? atoi(argv[4]) : 8;
+        std::vector<pq_rec1> T1(H2Y_T1_NREC);
+        pq_build_table1(T1.data());
+        std::atomic<uint64_t> wrong{0}, flagged{0};
+        std::vector<double> worst(T, 0.0);
+        std::vector<std::thread> th;
+        uint64_t span = (uint64_t)hi - lo;
+        for (int t = 0; t < T; t++)
+            th.emplace_back([&, t]() {
+                uint64_t a = lo + span * t / T, b = lo + span * (t + 1) / T, wr = 0, fl = 0;
+                double w = 0;
+                for (uint64_t u = a; u < b; u++) {
+                    float x = bits2f((uint32_t)u), want;
+                    double vref = ref_chain(x, &want);
+                    bool uns;
+                    float got = pq_t1(x, T1.data(), &uns);
+                    if (uns) fl++;
+                    else if (f2bits(got) != f2bits(want)) {
+                        if (wr++ < 3) fprintf(stderr, "T1 WRONG x=%a got %a want %a\n", x, got, want);
+                    }
+                    float c0h, ww;
+                    uint32_t off = pq_t1_offset((uint32_t)u) >> 4;
+                    if (off < H2Y_T1_NSEG) {
+                        pq_t1_parts((uint32_t)u, T1[off], &c0h, &ww);
+                        double e = fabs(((double)c0h + (double)ww) - vref) / vref;
+                        if (e > w) w = e;
+                    }
+                }
+                wrong += wr; flagged += fl; worst[t] = w;
+            });
+        for (auto &x : th) x.join();
+        double w = 0; for (double x : worst) w = fmax(w, x);
+        printf("T1 over [0x%08x,0x%08x): wrong %llu, flagged %llu of %llu (%.3f%%), max |c0h+w - ref|/ref = %.4g (2^%.2f)\n", lo, hi,
+               (unsigned long long)wrong.load(), (unsigned long long)flagged.load(), (unsigned long long)span, 100.0 * flagged.load() / span, w, log2(w));
+        return wrong.load() ? 1 : 0;
+    }
     if (!strcmp(argv[1], "tf")) {
         /* the other transfer functions (careful tier only) against libm, random inputs in [0, 1.25) */
         long n = argc > 2 ? atol(argv[2]) : 2000000;

@@ -492,6 +492,8 @@ inline void pq_build_table(pq_recA *A, pq_recB *B)
 #define H2Y_T1_NREC (H2Y_T1_NSEG + 1)
 #define H2Y_T1_BASE ((uint32_t)(127 + H2Y_PQ_EMIN) << H2Y_T1_SEG_BITS)
 #define H2Y_T1_RELERR 2.9e-10f /* measured max 2.523e-10 over every float of the domain (tools/pq_check t1), +15 % */
+/* mantissa bits of 2 (1 - RELERR 2^25) = 1.980538, rounded down */
+#define H2Y_T1_THR_MANT 0x007D8248u
 struct alignas(16) pq_rec1 {
     float c0h, c0l, c1, c2;
 };
@@ -515,9 +517,10 @@ H2Y_FN float pq_t1(float x, const pq_rec1 *__restrict__ T, bool *unsure)
     float c0h, w;
     pq_t1_parts(bits, r, &c0h, &w);
     const float s = c0h + w;
-    const float e = w - (s - c0h);                                          /* exact: |c0h| >= |w| */
-    const float half_ulp = bits2f((f2bits(s) & 0x7F800000u) - (24u << 23)); /* 2^(E-24) */
-    const float thr = __builtin_fmaf(s, -H2Y_T1_RELERR, half_ulp);
+    const float e = w - (s - c0h); /* exact: |c0h| >= |w| */
+    /* ulp(s)/2 - delta with delta = RELERR*s <= RELERR * 2^25 * ulp(s)/2: one constant factor
+     * (1 - RELERR*2^25) of ulp(s)/2, built from s's exponent and that factor's mantissa */
+    const float thr = bits2f(((f2bits(s) & 0x7F800000u) | H2Y_T1_THR_MANT) - (25u << 23));
     *unsure = !(__builtin_fabsf(e) < thr); /* NaN (sentinel record) => unsure */
     return s;
 }
@@ -748,10 +751,11 @@ H2Y_FN bool pix_matrix_t1(const pix_params &pp, const t1_sens &sn, float G, floa
     Cro = chroma_clamped(sat_i32_f64(qr), pp.half_m1, pp.maxCV);
     const uint32_t fb = (uint32_t)(d2bits(fract_f64(qb)) >> 32), fr = (uint32_t)(d2bits(fract_f64(qr)) >> 32);
     const bool y_unsafe = !(__builtin_fabsf(fract_f32(ylike) - 0.5f) < sn.ty); /* NaN => unsafe */
-    const bool cb_unsafe = (fb - (vunc ? sn.cb_lo : H2Y_GUARD_LO)) >= (vunc ? sn.cb_span : H2Y_GUARD_SPAN);
-    const bool cr_unsafe = (fr - (vunc ? sn.cr_lo : H2Y_GUARD_LO)) >= (vunc ? sn.cr_span : H2Y_GUARD_SPAN);
+    /* the narrow window (the division guard) lies inside the wide one (the one-ulp sensitivity) */
+    const bool wide = ((fb - sn.cb_lo) >= sn.cb_span) | ((fr - sn.cr_lo) >= sn.cr_span);
+    const bool narrow = ((fb - H2Y_GUARD_LO) >= H2Y_GUARD_SPAN) | ((fr - H2Y_GUARD_LO) >= H2Y_GUARD_SPAN);
     /* YDzDx has no division, so without an unsure sample its chroma needs no guard at all */
-    const bool guard = MODE == H2Y_MODE_YCBCR ? (cb_unsafe | cr_unsafe) : (vunc & (cb_unsafe | cr_unsafe));
+    const bool guard = MODE == H2Y_MODE_YCBCR ? (wide & (vunc | narrow)) : (vunc & wide);
     return guard | (vunc & y_unsafe);
 }
 

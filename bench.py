@@ -180,7 +180,7 @@ def main():
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)   # max over ranks
             dist.all_reduce(px, op=dist.ReduceOp.SUM)  # pixels all ranks processed (RCCL over xGMI)
-        results[res] = dict(secs=float(t.item()), pixels=float(px.item()), kernel_ms=kernel_ms, redone=redone,
+        results[res] = dict(secs=float(t.item()), pixels=float(px.item()), kernel_ms=kernel_ms, redone=redone, kernel=ctx.last_kernel_name(),
                             checksum=int(outs_t[0][:4096].to(torch.int64).sum().item()))
         del outs_t
 
@@ -224,7 +224,7 @@ def main():
             traffic = None
     out["roofline"] = {
         "bound": "hbm",
-        "kernel": "k_fused",
+        "kernel": main_r["kernel"],
         "achieved": round(ach, 1),
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",

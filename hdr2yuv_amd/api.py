@@ -27,7 +27,7 @@ H2Y_OK, H2Y_EINVAL, H2Y_EUNSUPPORTED, H2Y_EHIP, H2Y_ENOMEM = 0, 1, 2, 3, 4
 EXPORTS = [
     "h2y_abi_version", "h2y_frame_bytes", "h2y_plane_bytes", "h2y_desc_check", "h2y_ctx_create", "h2y_ctx_destroy",
     "h2y_last_error", "h2y_ctx_set_stream", "h2y_convert_frame", "h2y_convert_batch", "h2y_convert_batch_enqueue",
-    "h2y_batch_finish", "h2y_pic_stats", "h2y_matrix_convert", "h2y_subsample_420", "h2y_last_kernel_ms",
+    "h2y_batch_finish", "h2y_pic_stats", "h2y_matrix_convert", "h2y_subsample_420", "h2y_last_kernel_ms", "h2y_last_kernel_name",
 ]
 
 
@@ -134,6 +134,8 @@ def load_library():
     L.h2y_matrix_convert.argtypes = [C.c_void_p, C.POINTER(H2YDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.h2y_subsample_420.restype = C.c_int
     L.h2y_subsample_420.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.h2y_last_kernel_name.restype = C.c_char_p
+    L.h2y_last_kernel_name.argtypes = [C.c_void_p]
     L.h2y_last_kernel_ms.restype = C.c_int
     L.h2y_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     _LIB = L
@@ -251,3 +253,6 @@ class Context:
         n = C.c_int()
         self.lib.h2y_last_kernel_ms(self.h, C.byref(ms), C.byref(n))
         return ms.value, n.value
+
+    def last_kernel_name(self) -> str:
+        return (self.lib.h2y_last_kernel_name(self.h) or b"").decode()

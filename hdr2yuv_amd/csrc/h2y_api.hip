@@ -98,6 +98,7 @@ struct h2y_ctx {
     hipEvent_t ev[kMaxEvents][2];
     int n_ev = 0;
     float last_ms = 0.f;
+    const char *last_name = "";
     int last_launches = 0;
     std::string err;
 };
@@ -320,7 +321,8 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frames + f0, ctx->h_frames + f0, nf * sizeof(frame_io), hipMemcpyHostToDevice,
                                     ctx->stream));
         const int grid = grid_for(ctx, var, (uint64_t)g.chunks * nf);
-        int rc = ensure(ctx, ctx->d_partial, ctx->partial_cap, (size_t)nf * grid * 6 * sizeof(float));
+        const int waves = h2y_fused_threads(var) / 64; /* the fused kernels leave one min/max record per wave */
+        int rc = ensure(ctx, ctx->d_partial, ctx->partial_cap, (size_t)nf * grid * waves * 6 * sizeof(float));
         if (rc) return rc;
         fused_args a;
         a.frames = ctx->d_frames + f0;
@@ -339,7 +341,10 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         a.assumed = d_assumed;
         a.pp = pp;
         const bool ev = time_it && ctx->n_ev < kMaxEvents;
-        if (ev) HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->n_ev][0], ctx->stream));
+        if (ev) {
+            HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->n_ev][0], ctx->stream));
+            ctx->last_name = h2y_fused_name(var);
+        }
         HIP_TRY(ctx, h2y_launch_fused(var, grid, ctx->stream, a));
         if (ev) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->n_ev][1], ctx->stream));
@@ -347,7 +352,7 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         }
         final_args fa;
         fa.partial = ctx->d_partial;
-        fa.nblk = grid;
+        fa.nblk = grid * waves;
         fa.out = ctx->d_fstats + fstats_offset + f0;
         fa.is_u16 = d->in_sample_type == H2Y_SAMPLE_U16;
         fa.src_bit_depth = d->src_bit_depth;
@@ -805,7 +810,7 @@ int h2y_matrix_convert(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3
     var.mode = pp.mode;
     var.narrow = (d->width % 4) != 0;
     var.pipe = (pp.convert_transfer == 1 && !var.narrow) ? 2 : 0;
-    const geom g = make_geom(d, H2Y_FUSED_THREADS);
+    const geom g = make_geom(d, h2y_fused_threads(var));
     frame_io io;
     for (int c = 0; c < 3; c++) io.in[c] = d_in[c];
     io.out = d_out444[0];
@@ -814,7 +819,7 @@ int h2y_matrix_convert(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3
     ctx->h_frames[0] = io;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frames, ctx->h_frames, sizeof(frame_io), hipMemcpyHostToDevice, ctx->stream));
     const int grid = grid_for(ctx, var, g.chunks);
-    rc = ensure(ctx, ctx->d_partial, ctx->partial_cap, (size_t)grid * 6 * sizeof(float));
+    rc = ensure(ctx, ctx->d_partial, ctx->partial_cap, (size_t)grid * (h2y_fused_threads(var) / 64) * 6 * sizeof(float));
     if (rc) return rc;
     fused_args a;
     a.frames = ctx->d_frames;
@@ -864,6 +869,8 @@ int h2y_subsample_420(h2y_ctx *ctx, int width, int height, int bit_depth, int ch
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return H2Y_OK;
 }
+
+const char *h2y_last_kernel_name(const h2y_ctx *ctx) { return ctx ? ctx->last_name : ""; }
 
 int h2y_last_kernel_ms(const h2y_ctx *ctx, float *ms, int *launches)
 {

@@ -100,6 +100,7 @@ struct fir_args {
 };
 
 int h2y_fused_threads(const fused_variant &v);
+const char *h2y_fused_name(const fused_variant &v);
 int h2y_fused_blocks_per_cu(const fused_variant &v);
 hipError_t h2y_launch_fused(const fused_variant &v, int grid, hipStream_t st, const fused_args &a);
 hipError_t h2y_launch_build_lut16(hipStream_t st, const void *table, float *lut);

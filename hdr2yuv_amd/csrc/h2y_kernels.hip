@@ -107,6 +107,22 @@ __device__ __forceinline__ void block_store_mm(mm6 &m, float *smem /* NWAVES*6 *
     __syncthreads();
 }
 
+/* Same, but per wave and with no barrier: the fused kernels' waves drift apart across
+ * frames instead of draining the CU's memory pipeline at every frame boundary.
+ * dst points at this wave's six floats; k_stats_final folds grid * waves entries. */
+__device__ __forceinline__ void wave_store_mm(mm6 &m, float *dst)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float a = wave_min(m.lo[c]), b = wave_max(m.hi[c]);
+        if (lane == 0) {
+            dst[2 * c] = a;
+            dst[2 * c + 1] = b;
+        }
+    }
+}
+
 /* ---- sample loads ------------------------------------------------------- */
 template <int KIND> struct in_traits;
 template <> struct in_traits<H2Y_IN_F32> {
@@ -417,7 +433,6 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
     __shared__ pq_recA s_tab[2 * H2Y_PQ_NREC]; /* A records, then B records */
     const pq_recA *sA = s_tab;
     const pq_recB *sB = reinterpret_cast<const pq_recB *>(s_tab + H2Y_PQ_NREC);
-    __shared__ float s_red[(H2Y_FUSED_THREADS / WAVE) * 6];
     __shared__ pix_params s_pp;
     if (PIPE != H2Y_PIPE_RUNTIME || a.pp.convert_transfer == 1) stage_table<H2Y_FUSED_THREADS>(a.table, s_tab);
     const pix_params pp = with_assumed(a.pp, a.assumed);
@@ -448,7 +463,7 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
             tile_exact<OUT_KIND, MODE, PIPE>(pp, &s_pp, sA, sB, v, o);
             tile_store<OUT_KIND>(io, t, W, H, o);
         }
-        block_store_mm<H2Y_FUSED_THREADS / WAVE>(mm, s_red, a.partial + ((size_t)f * G + blockIdx.x) * 6);
+        wave_store_mm(mm, a.partial + (((size_t)f * G + blockIdx.x) * (H2Y_FUSED_THREADS / WAVE) + threadIdx.x / WAVE) * 6);
     }
 }
 
@@ -500,7 +515,6 @@ template <int IN_KIND, int OUT_KIND, int MODE, int PIPE>
 __global__ __launch_bounds__(H2Y_T1_THREADS, 4) void k_fused_t1(fused_args a)
 {
     __shared__ pq_rec1 s_t1[H2Y_T1_NREC];
-    __shared__ float s_red[(H2Y_T1_THREADS / WAVE) * 6];
     __shared__ pix_params s_pp;
     {
         const uint4 *g = reinterpret_cast<const uint4 *>(a.table1);
@@ -547,7 +561,7 @@ __global__ __launch_bounds__(H2Y_T1_THREADS, 4) void k_fused_t1(fused_args a)
             }
             tile_store<OUT_KIND>(io, t, W, H, o);
         }
-        block_store_mm<H2Y_T1_THREADS / WAVE>(mm, s_red, a.partial + ((size_t)f * G + blockIdx.x) * 6);
+        wave_store_mm(mm, a.partial + (((size_t)f * G + blockIdx.x) * (H2Y_T1_THREADS / WAVE) + threadIdx.x / WAVE) * 6);
     }
 }
 
@@ -581,7 +595,6 @@ template <int OUT_KIND, int MODE>
 __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused_lut16(fused_args a)
 {
     __shared__ float s_lut[H2Y_LUT16_N];
-    __shared__ float s_red[(H2Y_FUSED_THREADS / WAVE) * 6];
     __shared__ pix_params s_pp;
     {
         const uint4 *g = reinterpret_cast<const uint4 *>(a.lut16);
@@ -653,7 +666,7 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
             mm.lo[c] = mm.lo[c] > 65504.0f ? 3.402823466e+38f : mm.lo[c]; /* still +inf: no sample was below FLT_MAX */
             mm.hi[c] = mm.hi[c] <= 0.0f ? 1.175494351e-38f : mm.hi[c];
         }
-        block_store_mm<H2Y_FUSED_THREADS / WAVE>(mm, s_red, a.partial + ((size_t)f * G + blockIdx.x) * 6);
+        wave_store_mm(mm, a.partial + (((size_t)f * G + blockIdx.x) * (H2Y_FUSED_THREADS / WAVE) + threadIdx.x / WAVE) * 6);
     }
 }
 
@@ -682,7 +695,6 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS) void k_fused_narrow(fused_args a
     __shared__ pq_recA s_tab[2 * H2Y_PQ_NREC]; /* A records, then B records */
     const pq_recA *sA = s_tab;
     const pq_recB *sB = reinterpret_cast<const pq_recB *>(s_tab + H2Y_PQ_NREC);
-    __shared__ float s_red[(H2Y_FUSED_THREADS / WAVE) * 6];
     __shared__ pix_params s_pp;
     if (a.pp.convert_transfer == 1) stage_table<H2Y_FUSED_THREADS>(a.table, s_tab);
     typedef in_traits<IN_KIND> IN;
@@ -722,7 +734,7 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS) void k_fused_narrow(fused_args a
                 }
             }
         }
-        block_store_mm<H2Y_FUSED_THREADS / WAVE>(mm, s_red, a.partial + ((size_t)f * G + blockIdx.x) * 6);
+        wave_store_mm(mm, a.partial + (((size_t)f * G + blockIdx.x) * (H2Y_FUSED_THREADS / WAVE) + threadIdx.x / WAVE) * 6);
     }
 }
 
@@ -974,6 +986,12 @@ template <int IN_KIND> static fused_fn pick_t1_out(int out_kind, int mode, int p
     case H2Y_OUT_444: return pick_t1_mode<IN_KIND, H2Y_OUT_444>(mode, pipe);
     default: return pick_t1_mode<IN_KIND, H2Y_OUT_444TMP>(mode, pipe);
     }
+}
+const char *h2y_fused_name(const fused_variant &v)
+{
+    if (v.narrow) return "k_fused_narrow";
+    if (v.pipe == 3) return "k_fused_lut16";
+    return (v.pipe == 4 || v.pipe == 5) ? "k_fused_t1" : "k_fused";
 }
 int h2y_fused_threads(const fused_variant &v) { return (v.pipe == 4 || v.pipe == 5) ? H2Y_T1_THREADS : H2Y_FUSED_THREADS; }
 

@@ -177,6 +177,10 @@ int h2y_subsample_420(h2y_ctx *ctx, int width, int height, int bit_depth,
  * launches that covered. */
 int h2y_last_kernel_ms(const h2y_ctx *ctx, float *ms, int *launches);
 
+/* Name of the kernel those launches ran ("k_fused", "k_fused_t1", "k_fused_lut16",
+ * "k_fused_narrow"): the name to look for in a rocprofv3 kernel trace. */
+const char *h2y_last_kernel_name(const h2y_ctx *ctx);
+
 #ifdef __cplusplus
 }
 #endif

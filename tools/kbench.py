@@ -66,6 +66,10 @@ def main():
                 p[0] = 0.0
                 p[1] = 1.0
         timeit(ctx, h.make_desc(w, hh, dst_depth=12, dst_matrix=9, resampler=0), sm, "C2 box smooth ramp input")
+    if on("c1"):
+        w1, h1 = 1920, 1080
+        s1 = [[torch.from_numpy(p).cuda() for p in synth_frame(w1, h1, k)] for k in range(F)]
+        timeit(ctx, h.make_desc(w1, h1, dst_depth=12, dst_matrix=9, resampler=0), s1, "1080p 12-bit 2020nc box (cache-resident when F small)")
     if on("c4"):
         w8, h8 = 7680, 4320
         f16 = [[torch.from_numpy(p.view(np.int16)).cuda() for p in synth_frame(w8, h8, k, f16=True)] for k in range(max(2, F // 4))]

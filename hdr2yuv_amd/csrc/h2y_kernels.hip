@@ -78,6 +78,14 @@ struct mm6 {
         lo[c] = min3f(lo[c], s, t);
         hi[c] = max3f(hi[c], s, t);
     }
+    /* the eight samples of one tile and channel: their own min/max come back too */
+    __device__ __forceinline__ void add8(int c, const float (&p)[4], const float (&q)[4], float &tlo, float &thi)
+    {
+        tlo = min3f(min3f(p[0], p[1], p[2]), min3f(p[3], q[0], q[1]), min3f(q[2], q[3], q[3]));
+        thi = max3f(max3f(p[0], p[1], p[2]), max3f(p[3], q[0], q[1]), max3f(q[2], q[3], q[3]));
+        lo[c] = min3f(lo[c], tlo, tlo);
+        hi[c] = max3f(hi[c], thi, thi);
+    }
 };
 
 /* Block-wide reduce of a thread's mm6 and one plain store of the six floats
@@ -472,47 +480,30 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
  * YCbCr or YDzDx, bit depths where t1_bounds() says it pays).
  *
  *   tier 1  pq_t1(): one 16-byte LDS record and ~16 binary32 instructions per
- *           sample give the reference's float for 99.3 % of samples and say so;
+ *           sample give the reference's float for 99 % of samples and say so;
  *           the matrix step is the exact one (pix_matrix_t1).  A pixel is final
  *           unless one of its samples was "unsure" AND one of its three integers
  *           could change with a one-ulp change of that sample (0.05 % of pixels
- *           at 12 bits), or the reciprocal-division guard fires.
- *   tier 2  such pixels go through pixel_fast<>() -- the binary64 polynomial --
- *           with its table read straight from HBM/L2 (rare, so no LDS copy),
- *   tier 3  and from there, as before, to pixel_careful().
+ *           at 12 bits), or the reciprocal-division guard fires.  The hot loop has
+ *           no branch for them: a tile holding such a pixel is appended to a per-
+ *           frame list (one atomic) and k_patch, a small second kernel, redoes the
+ *           listed tiles with
+ *   tier 2  pixel_fast<>() -- the binary64 polynomial, table from HBM/L2 -- and
+ *   tier 3  pixel_careful(), as k_fused does.
+ *   Tiles with a sample outside the T1 table (+0.0 above all: black bars) are
+ *   common in real pictures, so they do not go to the list: the tile-local
+ *   min/max (already needed for pic_stats) sends the whole tile through tiers
+ *   2/3 at once, out of line (tile_t23).
  *
  * 1024 threads per block, one block per CU: the T1 table (256 segments per
  * binade) takes 100 KB of LDS.
  */
 #define H2Y_T1_THREADS 1024
-/* tiers 2 and 3 for one pixel, out of line: parameters come from the block's LDS copy and
- * the binary64 table from HBM/L2, so the hot loop carries none of their registers */
-template <int MODE>
-__device__ __attribute__((noinline)) ycc pixel_t23(const pix_params *spp, const void *table, float G, float B, float R)
-{
-    const pix_params &pp = *spp;
-    const pq_recA *gA = static_cast<const pq_recA *>(table);
-    const pq_recB *gB = reinterpret_cast<const pq_recB *>(gA + H2Y_PQ_NREC);
-    ycc o;
-    if (pixel_fast<MODE, H2Y_PIPE_PQ_IDENT>(pp, gA, gB, G, B, R, o.y, o.cb, o.cr)) return pixel_careful<MODE>(spp, G, B, R);
-    return o;
-}
-template <int MODE>
-__device__ __forceinline__ void pixel_t1(const pix_params &pp, const t1_sens &sn, const pix_params *spp, const pq_rec1 *sT1,
-                                         const void *table, float G, float B, float R, uint32_t &Y, uint32_t &Cb, uint32_t &Cr)
-{
-    bool ug, ub, ur;
-    const float g = pix_scale(pq_t1(G, sT1, &ug), pp.mulY, pp.addY);
-    const float b = pix_scale(pq_t1(B, sT1, &ub), pp.mulC, pp.addC);
-    const float r = pix_scale(pq_t1(R, sT1, &ur), pp.mulC, pp.addC);
-    if (__builtin_expect(pix_matrix_t1<MODE>(pp, sn, g, b, r, ug | ub | ur, Y, Cb, Cr), 0)) {
-        const ycc c = pixel_t23<MODE>(spp, table, G, B, R);
-        Y = c.y; Cb = c.cb; Cr = c.cr;
-    }
-}
-
+#ifndef H2Y_T1_SCHED_GROUP
+#define H2Y_T1_SCHED_GROUP 0 /* >0: scheduling barrier after every so many pixels of k_fused_t1's tile loop */
+#endif
 template <int IN_KIND, int OUT_KIND, int MODE, int PIPE>
-__global__ __launch_bounds__(H2Y_T1_THREADS, 4) void k_fused_t1(fused_args a)
+__global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
 {
     __shared__ pq_rec1 s_t1[H2Y_T1_NREC];
     __shared__ pix_params s_pp;
@@ -546,6 +537,7 @@ __global__ __launch_bounds__(H2Y_T1_THREADS, 4) void k_fused_t1(fused_args a)
                 mm.add2(2, v.r0[j], v.r1[j]);
             }
             tile_out o;
+            uint32_t redo_n = 0;
 #pragma unroll
             for (int jb = 0; jb < 2; jb++) {
                 uint32_t Y[4], Cb[4], Cr[4];
@@ -555,13 +547,82 @@ __global__ __launch_bounds__(H2Y_T1_THREADS, 4) void k_fused_t1(fused_args a)
                     const float Gn = norm1<PIPE>(pp, 0, q < 2 ? v.g0[col] : v.g1[col]);
                     const float Bn = norm1<PIPE>(pp, 1, q < 2 ? v.b0[col] : v.b1[col]);
                     const float Rn = norm1<PIPE>(pp, 2, q < 2 ? v.r0[col] : v.r1[col]);
-                    pixel_t1<MODE>(pp, sn, &s_pp, s_t1, a.table, Gn, Bn, Rn, Y[q], Cb[q], Cr[q]);
+                    bool ug, ub, ur;
+                    const float g = pix_scale(pq_t1(Gn, s_t1, &ug), pp.mulY, pp.addY);
+                    const float b = pix_scale(pq_t1(Bn, s_t1, &ub), pp.mulC, pp.addC);
+                    const float r = pix_scale(pq_t1(Rn, s_t1, &ur), pp.mulC, pp.addC);
+                    redo_n += pix_matrix_t1<MODE>(pp, sn, g, b, r, ug | ub | ur, Y[q], Cb[q], Cr[q]) ? 1u : 0u;
+                    /* pin the count here: left alone, the compiler postpones every pixel's guard arithmetic
+                     * to the end of the tile and keeps its operands alive until then (register spills) */
+                    asm volatile("" : "+v"(redo_n));
+#if H2Y_T1_SCHED_GROUP
+                    /* keep the scheduler from interleaving all eight pixels (it runs out of registers) */
+                    if ((q % H2Y_T1_SCHED_GROUP) == H2Y_T1_SCHED_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
+#endif
                 }
                 tile_pack<OUT_KIND>(pp, jb, Y, Cb, Cr, o);
             }
             tile_store<OUT_KIND>(io, t, W, H, o);
+            /* tiles to redo (a few lanes of about one wave in four at 12 bits; whole waves on black bars):
+             * every wave leaves its 64-bit lane mask, zero or not, in its own slot -- no atomics, no
+             * counters.  tt = 64 * slot + lane. */
+            const uint64_t m = __ballot(redo_n != 0);
+            if ((threadIdx.x & (WAVE - 1)) == 0) a.patch_mask[(size_t)f * a.patch_stride + tt / WAVE] = m;
         }
         wave_store_mm(mm, a.partial + (((size_t)f * G + blockIdx.x) * (H2Y_T1_THREADS / WAVE) + threadIdx.x / WAVE) * 6);
+    }
+}
+
+/*
+ * k_patch: the tiles k_fused_t1 flagged, redone by the exact tiers (tables from HBM/L2) and
+ * stored over T1's provisional output.  grid = (ceil(slots / 256), n_frames).  A block reads
+ * 256 wave masks, expands the set bits into a compact tile list in LDS (block prefix sum) and
+ * then works through that list with all its lanes busy.
+ */
+#define H2Y_PATCH_THREADS 256
+template <int IN_KIND, int OUT_KIND, int MODE, int PIPE>
+__global__ __launch_bounds__(H2Y_PATCH_THREADS) void k_patch(fused_args a)
+{
+    __shared__ pix_params s_pp;
+    __shared__ uint32_t s_list[H2Y_PATCH_THREADS * WAVE];
+    __shared__ uint32_t s_wave_total[H2Y_PATCH_THREADS / WAVE];
+    const pix_params pp = with_assumed(a.pp, a.assumed);
+    if (threadIdx.x == 0) s_pp = pp;
+    const int f = blockIdx.y;
+    const uint32_t n_slots = (a.tiles_per_frame + WAVE - 1) / WAVE;
+    const uint32_t slot = blockIdx.x * H2Y_PATCH_THREADS + threadIdx.x;
+    const uint64_t m = slot < n_slots ? a.patch_mask[(size_t)f * a.patch_stride + slot] : 0ull;
+    const uint32_t lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    /* exclusive prefix sum of the popcounts over the block */
+    const uint32_t c = (uint32_t)__popcll(m);
+    uint32_t incl = c;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const uint32_t up = __shfl_up(incl, o, WAVE);
+        if (lane >= (uint32_t)o) incl += up;
+    }
+    if (lane == WAVE - 1) s_wave_total[wave] = incl;
+    __syncthreads();
+    uint32_t off = incl - c, total = 0;
+#pragma unroll
+    for (int w = 0; w < H2Y_PATCH_THREADS / WAVE; w++) {
+        const uint32_t t = s_wave_total[w];
+        if ((uint32_t)w < wave) off += t;
+        total += t;
+    }
+    for (uint64_t r = m; r; r &= r - 1) s_list[off++] = slot * WAVE + (uint32_t)__ffsll((unsigned long long)r) - 1u;
+    __syncthreads();
+    if (total == 0) return;
+    const frame_io io = a.frames[f];
+    const pq_recA *gA = static_cast<const pq_recA *>(a.table);
+    const pq_recB *gB = reinterpret_cast<const pq_recB *>(gA + H2Y_PQ_NREC);
+    for (uint32_t i = threadIdx.x; i < total; i += H2Y_PATCH_THREADS) {
+        const tile_pos t = tile_locate(s_list[i], a.width, a.height, a.wq, a.wq_magic);
+        tile_in v;
+        tile_load<IN_KIND>(io, t, v);
+        tile_out o;
+        tile_exact<OUT_KIND, MODE, PIPE>(pp, &s_pp, gA, gB, v, o);
+        tile_store<OUT_KIND>(io, t, a.width, a.height, o);
     }
 }
 
@@ -986,6 +1047,28 @@ template <int IN_KIND> static fused_fn pick_t1_out(int out_kind, int mode, int p
     case H2Y_OUT_444: return pick_t1_mode<IN_KIND, H2Y_OUT_444>(mode, pipe);
     default: return pick_t1_mode<IN_KIND, H2Y_OUT_444TMP>(mode, pipe);
     }
+}
+template <int IN_KIND, int OUT_KIND> static fused_fn pick_patch_mode(int mode, int pipe)
+{
+    if (mode == H2Y_MODE_YCBCR)
+        return pipe == 4 ? k_patch<IN_KIND, OUT_KIND, H2Y_MODE_YCBCR, H2Y_PIPE_PQ_IDENT> : k_patch<IN_KIND, OUT_KIND, H2Y_MODE_YCBCR, H2Y_PIPE_PQ_NORM>;
+    return pipe == 4 ? k_patch<IN_KIND, OUT_KIND, H2Y_MODE_YDZDX, H2Y_PIPE_PQ_IDENT> : k_patch<IN_KIND, OUT_KIND, H2Y_MODE_YDZDX, H2Y_PIPE_PQ_NORM>;
+}
+template <int IN_KIND> static fused_fn pick_patch_out(int out_kind, int mode, int pipe)
+{
+    switch (out_kind) {
+    case H2Y_OUT_420BOX: return pick_patch_mode<IN_KIND, H2Y_OUT_420BOX>(mode, pipe);
+    case H2Y_OUT_444: return pick_patch_mode<IN_KIND, H2Y_OUT_444>(mode, pipe);
+    default: return pick_patch_mode<IN_KIND, H2Y_OUT_444TMP>(mode, pipe);
+    }
+}
+bool h2y_fused_needs_patch(const fused_variant &v) { return !v.narrow && (v.pipe == 4 || v.pipe == 5); }
+hipError_t h2y_launch_patch(const fused_variant &v, hipStream_t st, const fused_args &a)
+{
+    fused_fn fn = v.in_kind == H2Y_IN_F16 ? pick_patch_out<H2Y_IN_F16>(v.out_kind, v.mode, v.pipe) : pick_patch_out<H2Y_IN_F32>(v.out_kind, v.mode, v.pipe);
+    const uint32_t n_slots = (a.tiles_per_frame + WAVE - 1) / WAVE;
+    hipLaunchKernelGGL(fn, dim3((n_slots + H2Y_PATCH_THREADS - 1) / H2Y_PATCH_THREADS, a.n_frames), dim3(H2Y_PATCH_THREADS), 0, st, a);
+    return hipGetLastError();
 }
 const char *h2y_fused_name(const fused_variant &v)
 {

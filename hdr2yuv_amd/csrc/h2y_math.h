@@ -416,7 +416,12 @@ H2Y_FN float pq_eval(float x, const pq_rec &r, bool *slow)
  * instead (x outside the table, or rounding too close to call). */
 H2Y_FN float pq_fast(float x, const pq_recA *__restrict__ A, const pq_recB *__restrict__ B, bool *slow)
 {
-    return pq_eval(x, pq_fetch(x, A, B), slow);
+    bool sl;
+    const float v = pq_eval(x, pq_fetch(x, A, B), &sl);
+    /* +0.0 (black bars, unused channels) is outside the table but common: its value is a constant */
+    const bool zero = f2bits(x) == 0u;
+    *slow = sl & !zero;
+    return zero ? bits2f(H2Y_PQ_AT_ZERO_BITS) : v;
 }
 
 /* Host-side table builder (context creation).  Per segment: interpolate the
@@ -491,6 +496,8 @@ inline void pq_build_table(pq_recA *A, pq_recB *B)
 #define H2Y_T1_NSEG (H2Y_PQ_NBINADES << H2Y_T1_SEG_BITS)
 #define H2Y_T1_NREC (H2Y_T1_NSEG + 1)
 #define H2Y_T1_BASE ((uint32_t)(127 + H2Y_PQ_EMIN) << H2Y_T1_SEG_BITS)
+/* smallest input of the table: 2^EMIN */
+#define H2Y_T1_DOMAIN_LO 0x1p-24f
 #define H2Y_T1_RELERR 2.9e-10f /* measured max 2.523e-10 over every float of the domain (tools/pq_check t1), +15 % */
 /* mantissa bits of 2 (1 - RELERR 2^25) = 1.980538, rounded down */
 #define H2Y_T1_THR_MANT 0x007D8248u
@@ -611,6 +618,17 @@ H2Y_FN int32_t sat_i32_f64(double v)
     return (int32_t)v;
 #endif
 }
+/* (int)v as the reference's x86-64 build computes it (cvttsd2si): NaN gives INT_MIN, the
+ * "integer indefinite".  The saturating convert gives 0 for NaN; out-of-range values differ too
+ * (INT_MAX instead of INT_MIN) but both clamp to maxCV in chroma_clamped().  Careful tier only:
+ * every NaN reaches it (a NaN PQ value is never "sure", a NaN quotient never passes the guard).
+ * NaNs are ordinary here: pic_stats' (int)max is 0 for a picture whose maximum is below 1.0,
+ * the range becomes 0 and matrix_convert() divides every sample by it (convert.cpp:939-1019). */
+H2Y_FN int32_t x86_i32_f64(double v)
+{
+    const int32_t r = sat_i32_f64(v);
+    return v != v ? (int32_t)0x80000000 : r;
+}
 /* x - floor(x) in [0,1) (v_fract_f32) */
 H2Y_FN float fract_f32(float v)
 {
@@ -692,8 +710,8 @@ H2Y_FN void pix_matrix(const pix_params &pp, float G, float B, float R, uint32_t
         float tmpF = (float)yd;
         Yo = f2u_clamped(tmpF, pp.maxCV);
         if (EXACT_DIV) {
-            cb = sat_i32_f64((double)(B - tmpF) / pp.dcb + 0.5);
-            cr = sat_i32_f64((double)(R - tmpF) / pp.dcr + 0.5);
+            cb = x86_i32_f64((double)(B - tmpF) / pp.dcb + 0.5);
+            cr = x86_i32_f64((double)(R - tmpF) / pp.dcr + 0.5);
         } else {
             bool u1, u2;
             cb = div_round_trunc_fast(B - tmpF, pp.inv_dcb, &u1);
@@ -703,12 +721,12 @@ H2Y_FN void pix_matrix(const pix_params &pp, float G, float B, float R, uint32_t
     } else if (mode == H2Y_MODE_YDZDX) {
         Yo = f2u_clamped(G, pp.maxCV);
         double hg = (double)(-G) * 0.5; /* -G/2.0: exact either way */
-        cb = sat_i32_f64((hg + (double)B * 0.5) + 0.5);
-        cr = sat_i32_f64((hg + (double)R * 0.5) + 0.5);
+        cb = EXACT_DIV ? x86_i32_f64((hg + (double)B * 0.5) + 0.5) : sat_i32_f64((hg + (double)B * 0.5) + 0.5);
+        cr = EXACT_DIV ? x86_i32_f64((hg + (double)R * 0.5) + 0.5) : sat_i32_f64((hg + (double)R * 0.5) + 0.5);
     } else {
         Yo = f2u_clamped(G, pp.maxCV);
-        cb = sat_i32_f64((double)(pp.P * G + pp.Q * B) + 0.5);
-        cr = sat_i32_f64((double)(pp.RR * R + pp.S * G) + 0.5);
+        cb = EXACT_DIV ? x86_i32_f64((double)(pp.P * G + pp.Q * B) + 0.5) : sat_i32_f64((double)(pp.P * G + pp.Q * B) + 0.5);
+        cr = EXACT_DIV ? x86_i32_f64((double)(pp.RR * R + pp.S * G) + 0.5) : sat_i32_f64((double)(pp.RR * R + pp.S * G) + 0.5);
     }
     Cbo = chroma_clamped(cb, pp.half_m1, pp.maxCV);
     Cro = chroma_clamped(cr, pp.half_m1, pp.maxCV);

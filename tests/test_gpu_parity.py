@@ -396,3 +396,40 @@ def test_rho_gamma_source_is_refused(ctx):
     with pytest.raises(h.H2YError) as e:
         ctx.convert_frame(d, [np.zeros(64 * 32, np.float32)] * 3)
     assert e.value.code == 2
+
+
+def _picture_like(rng, w, hh):
+    """Random picture with what real material has and uniform noise has not: black bars (+0.0),
+    a saturated patch with unused channels, out-of-gamut negatives, over-range highlights."""
+    planes = [rng.uniform(0.0, 1.0, (hh, w)).astype(np.float32) for _ in range(3)]
+    bar = max(2, hh // 8)
+    for p in planes:
+        p[:bar, :] = 0.0
+        p[-bar:, :] = 0.0
+    planes[0][bar:bar + 6, 8:40] = 0.0           # pure blue/red patch: G unused
+    planes[1][bar + 6:bar + 10, 16:24] = -0.0     # negative zero
+    planes[2][bar + 10:bar + 12, 4:12] = np.float32(-0.125)
+    planes[1][bar + 12:bar + 14, 40:48] = np.float32(1.75)
+    planes[0][bar + 14, 3] = np.float32(2.0 ** -26)
+    planes[2][bar + 14, 5] = np.float32(1e-41)    # denormal
+    return [p.reshape(-1) for p in planes]
+
+
+@pytest.mark.parametrize("depth,mat,chroma,res", [(12, h.MATRIX_BT2020NC, h.CHROMA_420, 0), (10, h.MATRIX_BT709, h.CHROMA_444, 0),
+                                                  (12, h.MATRIX_BT2020NC, h.CHROMA_420, 1), (10, h.MATRIX_YDZDX, h.CHROMA_420, 0),
+                                                  (16, h.MATRIX_YDZDX, h.CHROMA_444, 0)])
+def test_black_bars_and_out_of_table_samples(ctx, oracle, depth, mat, chroma, res):
+    """First-tier kernel: tiles holding +0.0 / negative / >= 2-adjacent samples leave the binary32
+    tier through the tile-level exit, the rest through the redo list; bytes still the oracle's."""
+    rng = np.random.default_rng(77 + depth)
+    w, hh = 264, 80
+    d = h.make_desc(w, hh, dst_depth=depth, dst_matrix=mat, chroma=chroma, resampler=res, stats=[(0, 1)] * 3)
+    planes = _picture_like(rng, w, hh)
+    got = ctx.convert_frame(d, planes)
+    want = oracle.convert_frame(_to_oracle_desc(d), planes)
+    assert np.array_equal(got, want), f"{np.count_nonzero(got != want)} samples differ"
+    # measured statistics (floor -0 -> 0, ceiling 1) and the normalising pipe
+    d2 = h.make_desc(w, hh, dst_depth=depth, dst_matrix=mat, chroma=chroma, resampler=res)
+    got = ctx.convert_frame(d2, planes)
+    want = oracle.convert_frame(_to_oracle_desc(d2), planes)
+    assert np.array_equal(got, want), f"{np.count_nonzero(got != want)} samples differ (measured stats)"

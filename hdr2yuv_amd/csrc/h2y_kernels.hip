@@ -132,37 +132,76 @@ __device__ __forceinline__ void wave_store_mm(mm6 &m, float *dst)
 }
 
 /* ---- sample loads ------------------------------------------------------- */
+/* Picture planes are addressed as GLOBAL memory, not through flat pointers: a flat load counts on
+ * the LDS counter as well (every table read would wait for the prefetched tile), and a global
+ * load takes a uniform base in scalar registers plus a 32-bit lane offset.  The plane pointers of
+ * a frame come out of memory, so the compiler cannot know either fact by itself. */
+#define H2Y_GLOBAL __attribute__((address_space(1)))
+/* index counts T's; with a 32-bit index the BYTE offset is formed in 32 bits too (pictures are
+ * limited to 2^28 samples), which is what lets the lane offset stay one register */
+template <typename T> __device__ __forceinline__ T gload(const void *base, uint32_t index)
+{
+    return *(const H2Y_GLOBAL T *)((const H2Y_GLOBAL char *)base + index * (uint32_t)sizeof(T));
+}
+template <typename T> __device__ __forceinline__ T gload(const void *base, size_t index)
+{
+    return *((const H2Y_GLOBAL T *)base + index);
+}
+template <typename T> __device__ __forceinline__ void gstore(void *base, uint32_t index, T v)
+{
+    *(H2Y_GLOBAL T *)((H2Y_GLOBAL char *)base + index * (uint32_t)sizeof(T)) = v;
+}
+/* a pointer every lane holds the same value of, moved to scalar registers */
+template <typename P> __device__ __forceinline__ P *uniform_ptr(P *p)
+{
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<P *>(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ frame_io uniform_io(const frame_io *p)
+{
+    frame_io io = *p;
+#pragma unroll
+    for (int c = 0; c < 3; c++) io.in[c] = uniform_ptr(io.in[c]);
+    io.out = uniform_ptr(io.out);
+    io.tmp_cb = uniform_ptr(io.tmp_cb);
+    io.tmp_cr = uniform_ptr(io.tmp_cr);
+    return io;
+}
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 template <int KIND> struct in_traits;
 template <> struct in_traits<H2Y_IN_F32> {
     typedef float T;
-    static __device__ __forceinline__ void load4(const void *p, size_t i, float v[4])
+    /* i: sample index, a multiple of 4 (16-byte aligned planes) */
+    template <typename I> static __device__ __forceinline__ void load4(const void *p, I i, float v[4])
     {
-        float4 q = *reinterpret_cast<const float4 *>(static_cast<const float *>(p) + i);
+        const f32x4 q = gload<f32x4>(p, i >> 2);
         v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
     }
-    static __device__ __forceinline__ float load1(const void *p, size_t i) { return static_cast<const float *>(p)[i]; }
+    template <typename I> static __device__ __forceinline__ float load1(const void *p, I i) { return gload<float>(p, i); }
 };
 template <> struct in_traits<H2Y_IN_F16> {
     typedef _Float16 T;
-    static __device__ __forceinline__ void load4(const void *p, size_t i, float v[4])
+    template <typename I> static __device__ __forceinline__ void load4(const void *p, I i, float v[4])
     {
         /* exr.cpp:233-235: half widened to float, exact */
         typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-        h4 q = *reinterpret_cast<const h4 *>(static_cast<const _Float16 *>(p) + i);
+        const h4 q = gload<h4>(p, i >> 2);
         v[0] = (float)q.x; v[1] = (float)q.y; v[2] = (float)q.z; v[3] = (float)q.w;
     }
-    static __device__ __forceinline__ float load1(const void *p, size_t i) { return (float)static_cast<const _Float16 *>(p)[i]; }
+    template <typename I> static __device__ __forceinline__ float load1(const void *p, I i) { return (float)gload<_Float16>(p, i); }
 };
 template <> struct in_traits<H2Y_IN_U16> {
     typedef uint16_t T;
-    static __device__ __forceinline__ void load4(const void *p, size_t i, float v[4])
+    template <typename I> static __device__ __forceinline__ void load4(const void *p, I i, float v[4])
     {
         /* convert.cpp:989-994: (float) of the unsigned short */
-        uint2 q = *reinterpret_cast<const uint2 *>(static_cast<const uint16_t *>(p) + i);
+        const u32x2 q = gload<u32x2>(p, i >> 2);
         v[0] = (float)(q.x & 0xFFFFu); v[1] = (float)(q.x >> 16);
         v[2] = (float)(q.y & 0xFFFFu); v[3] = (float)(q.y >> 16);
     }
-    static __device__ __forceinline__ float load1(const void *p, size_t i) { return (float)static_cast<const uint16_t *>(p)[i]; }
+    template <typename I> static __device__ __forceinline__ float load1(const void *p, I i) { return (float)gload<uint16_t>(p, i); }
 };
 
 /* ---- one pixel: normalise -> PQ -> scale -> matrix ---------------------- */
@@ -283,7 +322,7 @@ template <int THREADS> __device__ __forceinline__ void stage_table(const void *t
 /* ---- the thread tile: 4 columns x 2 rows ------------------------------- */
 struct tile_pos {
     uint32_t rp, x; /* row pair, first column */
-    size_t i0, i1;  /* sample index of row 0 / row 1 (row 1 == row 0 when the picture ends) */
+    uint32_t i0, i1; /* sample index of row 0 / row 1 (row 1 == row 0 when the picture ends); pictures hold < 2^28 samples */
     bool row1;
 };
 __device__ __forceinline__ tile_pos tile_locate(uint32_t tt, uint32_t W, uint32_t H, uint32_t WQ, uint32_t magic)
@@ -294,7 +333,7 @@ __device__ __forceinline__ tile_pos tile_locate(uint32_t tt, uint32_t W, uint32_
     t.x = cg * 4;
     const uint32_t y = t.rp * 2;
     t.row1 = (y + 1) < H;
-    t.i0 = (size_t)y * W + t.x;
+    t.i0 = y * W + t.x;
     t.i1 = t.row1 ? t.i0 + W : t.i0;
     return t;
 }
@@ -344,24 +383,24 @@ __device__ __forceinline__ void tile_pack(const pix_params &pp, int jb, const ui
 template <int OUT_KIND>
 __device__ __forceinline__ void tile_store(const frame_io &io, const tile_pos &t, uint32_t W, uint32_t H, const tile_out &o)
 {
-    const size_t npix = (size_t)W * H;
-    uint16_t *Yp = io.out;
-    *reinterpret_cast<uint2 *>(Yp + t.i0) = make_uint2(o.yp0[0], o.yp0[1]);
-    if (t.row1) *reinterpret_cast<uint2 *>(Yp + t.i1) = make_uint2(o.yp1[0], o.yp1[1]);
+    /* offsets in units of u32x2 (four samples) from the start of the frame's output: < 2^32 bytes */
+    const uint32_t npix = W * H;
+    gstore<u32x2>(io.out, t.i0 >> 2, u32x2{o.yp0[0], o.yp0[1]});
+    if (t.row1) gstore<u32x2>(io.out, t.i1 >> 2, u32x2{o.yp1[0], o.yp1[1]});
     if (OUT_KIND == H2Y_OUT_420BOX) {
         const uint32_t wc = W >> 1;
-        const size_t ic = (size_t)t.rp * wc + (t.x >> 1);
-        uint16_t *Cbp = io.out + npix, *Crp = Cbp + (size_t)wc * (H >> 1);
-        *reinterpret_cast<uint32_t *>(Cbp + ic) = o.cb_box;
-        *reinterpret_cast<uint32_t *>(Crp + ic) = o.cr_box;
+        const uint32_t ic = t.rp * wc + (t.x >> 1); /* even: two chroma samples per tile */
+        const uint32_t ncb = wc * (H >> 1);
+        gstore<uint32_t>(io.out, (npix + ic) >> 1, o.cb_box);
+        gstore<uint32_t>(io.out, (npix + ncb + ic) >> 1, o.cr_box);
     } else {
         uint16_t *Cbp = OUT_KIND == H2Y_OUT_444 ? io.out + npix : io.tmp_cb;
-        uint16_t *Crp = OUT_KIND == H2Y_OUT_444 ? io.out + 2 * npix : io.tmp_cr;
-        *reinterpret_cast<uint2 *>(Cbp + t.i0) = make_uint2(o.cbp0[0], o.cbp0[1]);
-        *reinterpret_cast<uint2 *>(Crp + t.i0) = make_uint2(o.crp0[0], o.crp0[1]);
+        uint16_t *Crp = OUT_KIND == H2Y_OUT_444 ? io.out + 2 * (size_t)npix : io.tmp_cr;
+        gstore<u32x2>(Cbp, t.i0 >> 2, u32x2{o.cbp0[0], o.cbp0[1]});
+        gstore<u32x2>(Crp, t.i0 >> 2, u32x2{o.crp0[0], o.crp0[1]});
         if (t.row1) {
-            *reinterpret_cast<uint2 *>(Cbp + t.i1) = make_uint2(o.cbp1[0], o.cbp1[1]);
-            *reinterpret_cast<uint2 *>(Crp + t.i1) = make_uint2(o.crp1[0], o.crp1[1]);
+            gstore<u32x2>(Cbp, t.i1 >> 2, u32x2{o.cbp1[0], o.cbp1[1]});
+            gstore<u32x2>(Crp, t.i1 >> 2, u32x2{o.crp1[0], o.crp1[1]});
         }
     }
 }
@@ -449,7 +488,7 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
 
     const uint32_t W = a.width, H = a.height, G = gridDim.x;
     for (int f = 0; f < a.n_frames; f++) {
-        const frame_io io = a.frames[f];
+        const frame_io io = uniform_io(a.frames + f);
         mm6 mm;
         mm.reset();
         /* first chunk of frame f owned by this block */
@@ -518,18 +557,59 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
     __syncthreads();
 
     const uint32_t W = a.width, H = a.height, G = gridDim.x;
+    /* The next tile's 96 bytes are requested before the current tile is worked on (the loop needs
+     * ~97 registers, the second tile_in fits under 128): with four waves per SIMD and one
+     * load-then-compute phase per tile, the memory latency was otherwise exposed. */
+    tile_in nxt;
+    bool have = false; /* nxt holds the tile this block meets next (uniform) */
     for (int f = 0; f < a.n_frames; f++) {
-        const frame_io io = a.frames[f];
+        const frame_io io = uniform_io(a.frames + f);
+        const frame_io io_next = uniform_io(a.frames + (f + 1 < a.n_frames ? f + 1 : f)); /* for the prefetch across the frame boundary */
         mm6 mm;
         mm.reset();
+        /* results of the previous tile, stored at the top of the NEXT iteration: memory operations
+         * complete in issue order, so stores issued after the prefetch would make the wait for the
+         * prefetched tile a wait for them as well */
+        bool pend = false;
+        tile_out o_prev;
+        tile_pos t_prev;
+        uint64_t m_prev = 0;
+        uint32_t slot_prev = 0;
         const uint32_t gbase = (uint32_t)(((uint64_t)f * a.chunks_per_frame) % G);
+        const uint32_t k_next_frame = (uint32_t)((blockIdx.x + G - (uint32_t)(((uint64_t)(f + 1) * a.chunks_per_frame) % G)) % G);
         uint32_t k = (blockIdx.x + G - gbase) % G;
+        if (!have && k < a.chunks_per_frame) /* nothing on its way (first tile of the launch, or a block that skipped frames) */
+            tile_load<IN_KIND>(io, tile_locate(umin32(k * H2Y_T1_THREADS + threadIdx.x, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic), nxt);
         for (; k < a.chunks_per_frame; k += G) {
             const uint32_t tt = k * H2Y_T1_THREADS + threadIdx.x;
-            if (tt >= a.tiles_per_frame) continue;
-            const tile_pos t = tile_locate(tt, W, H, a.wq, a.wq_magic);
-            tile_in v;
-            tile_load<IN_KIND>(io, t, v);
+            const bool valid = tt < a.tiles_per_frame;
+            /* lanes past the end of the frame load its last tile again (no divergence around the loads) */
+            const tile_pos t = tile_locate(umin32(tt, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
+            const tile_in v = nxt;
+            if (pend) {
+                tile_store<OUT_KIND>(io, t_prev, W, H, o_prev);
+                if ((threadIdx.x & (WAVE - 1)) == 0) a.patch_mask[(size_t)f * a.patch_stride + slot_prev] = m_prev;
+            }
+            pend = valid;
+            {
+                /* Where does this block go next: k + G in this frame, else its first chunk of the next
+                 * frame.  The request is unconditional (a branch around it makes the compiler wait for the
+                 * data on the spot): when there is no next tile, this tile is simply asked for again. */
+                uint32_t k2 = k + G;
+                const bool same = k2 < a.chunks_per_frame;
+                if (!same) k2 = k_next_frame;
+                have = same || (f + 1 < a.n_frames && k2 < a.chunks_per_frame);
+                if (!have) k2 = k;
+                const uint32_t tt2 = umin32(k2 * H2Y_T1_THREADS + threadIdx.x, a.tiles_per_frame - 1u);
+                const tile_pos t2 = tile_locate(tt2, W, H, a.wq, a.wq_magic);
+                frame_io src = io;
+                if (!same && have) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) src.in[c] = io_next.in[c];
+                }
+                tile_load<IN_KIND>(src, t2, nxt);
+            }
+            if (!valid) continue;
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 mm.add2(0, v.g0[j], v.g1[j]);
@@ -562,12 +642,17 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
                 }
                 tile_pack<OUT_KIND>(pp, jb, Y, Cb, Cr, o);
             }
-            tile_store<OUT_KIND>(io, t, W, H, o);
             /* tiles to redo (a few lanes of about one wave in four at 12 bits; whole waves on black bars):
              * every wave leaves its 64-bit lane mask, zero or not, in its own slot -- no atomics, no
              * counters.  tt = 64 * slot + lane. */
-            const uint64_t m = __ballot(redo_n != 0);
-            if ((threadIdx.x & (WAVE - 1)) == 0) a.patch_mask[(size_t)f * a.patch_stride + tt / WAVE] = m;
+            o_prev = o;
+            t_prev = t;
+            m_prev = __ballot(redo_n != 0);
+            slot_prev = tt / WAVE;
+        }
+        if (pend) {
+            tile_store<OUT_KIND>(io, t_prev, W, H, o_prev);
+            if ((threadIdx.x & (WAVE - 1)) == 0) a.patch_mask[(size_t)f * a.patch_stride + slot_prev] = m_prev;
         }
         wave_store_mm(mm, a.partial + (((size_t)f * G + blockIdx.x) * (H2Y_T1_THREADS / WAVE) + threadIdx.x / WAVE) * 6);
     }
@@ -613,7 +698,7 @@ __global__ __launch_bounds__(H2Y_PATCH_THREADS) void k_patch(fused_args a)
     for (uint64_t r = m; r; r &= r - 1) s_list[off++] = slot * WAVE + (uint32_t)__ffsll((unsigned long long)r) - 1u;
     __syncthreads();
     if (total == 0) return;
-    const frame_io io = a.frames[f];
+    const frame_io io = uniform_io(a.frames + f);
     const pq_recA *gA = static_cast<const pq_recA *>(a.table);
     const pq_recB *gB = reinterpret_cast<const pq_recB *>(gA + H2Y_PQ_NREC);
     for (uint32_t i = threadIdx.x; i < total; i += H2Y_PATCH_THREADS) {
@@ -668,7 +753,7 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
 
     const uint32_t W = a.width, H = a.height, G = gridDim.x;
     for (int f = 0; f < a.n_frames; f++) {
-        const frame_io io = a.frames[f];
+        const frame_io io = uniform_io(a.frames + f);
         /* packed-half accumulators: {min, max} x plane, two halves per dword */
         uint32_t mn[3], mx[3];
 #pragma unroll
@@ -686,8 +771,8 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
             uint2 raw[3][2];
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                raw[c][0] = *reinterpret_cast<const uint2 *>(static_cast<const uint16_t *>(io.in[c]) + t.i0);
-                raw[c][1] = *reinterpret_cast<const uint2 *>(static_cast<const uint16_t *>(io.in[c]) + t.i1);
+                { const u32x2 q0 = gload<u32x2>(io.in[c], t.i0 >> 2); raw[c][0] = make_uint2(q0.x, q0.y); }
+                { const u32x2 q1 = gload<u32x2>(io.in[c], t.i1 >> 2); raw[c][1] = make_uint2(q1.x, q1.y); }
                 mn[c] = pk_min_h(pk_min_h(mn[c], raw[c][0].x), pk_min_h(raw[c][0].y, pk_min_h(raw[c][1].x, raw[c][1].y)));
                 mx[c] = pk_max_h(pk_max_h(mx[c], raw[c][0].x), pk_max_h(raw[c][0].y, pk_max_h(raw[c][1].x, raw[c][1].y)));
             }
@@ -766,7 +851,7 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS) void k_fused_narrow(fused_args a
     const size_t npix = (size_t)W * H;
     const uint32_t G = gridDim.x;
     for (int f = 0; f < a.n_frames; f++) {
-        const frame_io io = a.frames[f];
+        const frame_io io = uniform_io(a.frames + f);
         mm6 mm;
         mm.reset();
         const uint32_t gbase = (uint32_t)(((uint64_t)f * a.chunks_per_frame) % G);

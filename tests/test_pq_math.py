@@ -47,7 +47,8 @@ def test_out_of_table_goes_to_slow_tier(pq_check):
         rc, out = _run(pq_check, "range", hex(lo), hex(hi), "2")
         assert rc == 0, out
         m = re.search(r": (\d+) floats, mismatches 0, slow tier (\d+)", out)
-        assert m and m.group(1) == m.group(2)
+        # +0.0 is the one out-of-table input the fast tier answers itself (a constant: black bars are common)
+        assert m and int(m.group(1)) - int(m.group(2)) == (1 if lo == 0 else 0)
 
 
 def test_slow_tier_sampled(pq_check):

@@ -220,6 +220,7 @@ void derive_params(const h2y_desc *d, pix_params *pp, bool stage_matrix_only)
             pp->ylo = oc.minVR; pp->yhi = oc.maxVR; pp->clo = oc.minVRC; pp->chi = oc.maxVRC;
         }
     }
+    pix_limits_finish(pp);
 }
 
 struct geom {

@@ -364,8 +364,8 @@ __device__ __forceinline__ void tile_pack(const pix_params &pp, int jb, const ui
     o.yp1[jb] = pix_yuv_clamp(pp, Y[2], false) | (pix_yuv_clamp(pp, Y[3], false) << 16);
     if (OUT_KIND == H2Y_OUT_420BOX) {
         /* convert.cpp:157-160: (a+b+c+d)/4, unsigned truncation; then write_yuv's clamp */
-        uint32_t cb = pix_yuv_clamp(pp, (Cb[0] + Cb[1] + Cb[2] + Cb[3]) >> 2, true);
-        uint32_t cr = pix_yuv_clamp(pp, (Cr[0] + Cr[1] + Cr[2] + Cr[3]) >> 2, true);
+        uint32_t cb = pix_box_clamp(pp, Cb[0] + Cb[1] + Cb[2] + Cb[3]);
+        uint32_t cr = pix_box_clamp(pp, Cr[0] + Cr[1] + Cr[2] + Cr[3]);
         if (jb == 0) { o.cb_box = cb; o.cr_box = cr; }
         else { o.cb_box |= cb << 16; o.cr_box |= cr << 16; }
     } else {

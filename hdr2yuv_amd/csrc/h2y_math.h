@@ -494,7 +494,7 @@ inline void pq_build_table(pq_recA *A, pq_recB *B)
 #define H2Y_T1_SEG_BITS 8
 #define H2Y_T1_LOW_BITS (23 - H2Y_T1_SEG_BITS)
 #define H2Y_T1_NSEG (H2Y_PQ_NBINADES << H2Y_T1_SEG_BITS)
-#define H2Y_T1_NREC (H2Y_T1_NSEG + 1)
+#define H2Y_T1_NREC (H2Y_T1_NSEG + 2) /* record 0 and record NSEG+1 are the sentinels */
 #define H2Y_T1_BASE ((uint32_t)(127 + H2Y_PQ_EMIN) << H2Y_T1_SEG_BITS)
 /* smallest input of the table: 2^EMIN */
 #define H2Y_T1_DOMAIN_LO 0x1p-24f
@@ -512,15 +512,26 @@ H2Y_FN void pq_t1_parts(uint32_t bits, const pq_rec1 &r, float *c0h, float *w)
     *w = __builtin_fmaf(__builtin_fmaf(r.c2, u, r.c1), u, r.c0l);
     *c0h = r.c0h;
 }
-H2Y_FN uint32_t pq_t1_offset(uint32_t bits)
+/* Byte offset of the sample's record.  The sample is first clamped, as a float, between the two
+ * sentinel inputs -- the last float segment below the table and 2.0, the first above it -- so
+ * zero, tiny, negative (all below), >= 2, +inf (above) and NaN (v_med3_f32 returns the minimum of
+ * the other two) all land on a sentinel record (NaN value: never "sure").  Three instructions:
+ * v_med3_f32, v_lshrrev_b32, v_lshl_add_u32. */
+#define H2Y_T1_LO_SENTINEL_BITS ((H2Y_T1_BASE - 1u) << H2Y_T1_LOW_BITS)
+H2Y_FN uint32_t pq_t1_offset(float x)
 {
-    uint32_t t = bits - (H2Y_T1_BASE << H2Y_T1_LOW_BITS);
-    return umin32(t >> H2Y_T1_LOW_BITS, (uint32_t)H2Y_T1_NSEG) << 4;
+    const float lo = bits2f(H2Y_T1_LO_SENTINEL_BITS);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float c = __builtin_amdgcn_fmed3f(x, lo, 2.0f);
+#else
+    const float c = !(x > lo) ? lo : (x < 2.0f ? x : 2.0f); /* NaN -> lo */
+#endif
+    return ((f2bits(c) >> H2Y_T1_LOW_BITS) << 4) - ((H2Y_T1_BASE - 1u) << 4);
 }
 H2Y_FN float pq_t1(float x, const pq_rec1 *__restrict__ T, bool *unsure)
 {
     const uint32_t bits = f2bits(x);
-    const pq_rec1 r = *reinterpret_cast<const pq_rec1 *>(reinterpret_cast<const char *>(T) + pq_t1_offset(bits));
+    const pq_rec1 r = *reinterpret_cast<const pq_rec1 *>(reinterpret_cast<const char *>(T) + pq_t1_offset(x));
     float c0h, w;
     pq_t1_parts(bits, r, &c0h, &w);
     const float s = c0h + w;
@@ -552,13 +563,17 @@ inline void pq_build_table1(pq_rec1 *T)
         const dd q1 = dd_add(ev[1], dd_mul_d(q2, -(wn[0] + wn[1])));
         const dd q0 = dd_add(dd_add(ev[0], dd_mul_d(ev[1], -wn[0])), dd_mul_d(q2, wn[0] * wn[1]));
         const double r = (double)(2 << H2Y_T1_SEG_BITS);
-        T[i].c0h = (float)q0.hi;
-        T[i].c0l = (float)((q0.hi - (double)T[i].c0h) + q0.lo);
-        T[i].c1 = (float)(q1.hi * r);
-        T[i].c2 = (float)(q2.hi * r * r);
+        pq_rec1 &o = T[i + 1]; /* record 0 is the low sentinel */
+        o.c0h = (float)q0.hi;
+        o.c0l = (float)((q0.hi - (double)o.c0h) + q0.lo);
+        o.c1 = (float)(q1.hi * r);
+        o.c2 = (float)(q2.hi * r * r);
     }
-    T[H2Y_T1_NSEG].c0h = bits2f(0x7FC00000u);
-    T[H2Y_T1_NSEG].c0l = T[H2Y_T1_NSEG].c1 = T[H2Y_T1_NSEG].c2 = 0.0f;
+    for (int i = 0; i < 2; i++) {
+        pq_rec1 &o = T[i ? H2Y_T1_NSEG + 1 : 0];
+        o.c0h = bits2f(0x7FC00000u);
+        o.c0l = o.c1 = o.c2 = 0.0f;
+    }
 }
 
 /* ------------------------------------------------------------------------
@@ -586,7 +601,17 @@ struct pix_params {
      * (0..maxCV when the output is full range) */
     int down_shift;
     uint32_t ylo, yhi, clo, chi;
+    /* the same limits on the UNSHIFTED value (pix_limits_finish): lo << s and (hi << s) | (2^s - 1),
+     * and for the 2x2 box sum of four chroma values (s + 2) */
+    uint32_t ylo_s, yhi_s, clo_s, chi_s, clo_b, chi_b;
 };
+inline void pix_limits_finish(pix_params *pp)
+{
+    const int s = pp->down_shift;
+    pp->ylo_s = pp->ylo << s; pp->yhi_s = (pp->yhi << s) | ((1u << s) - 1u);
+    pp->clo_s = pp->clo << s; pp->chi_s = (pp->chi << s) | ((1u << s) - 1u);
+    pp->clo_b = pp->clo << (s + 2); pp->chi_b = (pp->chi << (s + 2)) | ((1u << (s + 2)) - 1u);
+}
 
 /* ---- conversions with the hardware's (defined) saturating behaviour --------
  * C leaves float->int casts undefined outside the target range; the kernels
@@ -742,6 +767,7 @@ struct t1_sens {
     float ty;                 /* luma safe iff |fract(y) - 0.5| < ty                     */
     uint32_t cb_lo, cb_span;  /* chroma unsafe iff (hiword(fract(q)) - lo) >= span (wide) */
     uint32_t cr_lo, cr_span;
+    uint32_t c_lo, c_span;    /* one window covering both (the wider of the two) */
 };
 #define H2Y_GUARD_LO 0x3E100000u                  /* hiword(2^-30): the always-on guard of the reciprocal division */
 #define H2Y_GUARD_SPAN (0x3FEFFFFFu - 0x3E100000u) /* up to hiword(1 - 2^-21) */
@@ -764,16 +790,23 @@ H2Y_FN bool pix_matrix_t1(const pix_params &pp, const t1_sens &sn, float G, floa
         qb = (hg + (double)B * 0.5) + 0.5;
         qr = (hg + (double)R * 0.5) + 0.5;
     }
-    Yo = f2u_clamped(ylike, pp.maxCV);
+    /* Y is left unclamped: the caller's pix_yuv_clamp() bounds it below maxCV anyway (yhi_s <= maxCV) */
+    Yo = (uint32_t)sat_i32_f32(ylike);
     Cbo = chroma_clamped(sat_i32_f64(qb), pp.half_m1, pp.maxCV);
     Cro = chroma_clamped(sat_i32_f64(qr), pp.half_m1, pp.maxCV);
     const uint32_t fb = (uint32_t)(d2bits(fract_f64(qb)) >> 32), fr = (uint32_t)(d2bits(fract_f64(qr)) >> 32);
     const bool y_unsafe = !(__builtin_fabsf(fract_f32(ylike) - 0.5f) < sn.ty); /* NaN => unsafe */
-    /* the narrow window (the division guard) lies inside the wide one (the one-ulp sensitivity) */
-    const bool wide = ((fb - sn.cb_lo) >= sn.cb_span) | ((fr - sn.cr_lo) >= sn.cr_span);
-    const bool narrow = ((fb - H2Y_GUARD_LO) >= H2Y_GUARD_SPAN) | ((fr - H2Y_GUARD_LO) >= H2Y_GUARD_SPAN);
-    /* YDzDx has no division, so without an unsure sample its chroma needs no guard at all */
-    const bool guard = MODE == H2Y_MODE_YCBCR ? (wide & (vunc | narrow)) : (vunc & wide);
+    bool guard;
+    if (MODE == H2Y_MODE_YCBCR) {
+        /* with an unsure sample the wide window (one-ulp sensitivity) applies, without one only the
+         * narrow window inside it (the guard of the reciprocal division); either chroma outside => redo */
+        const uint32_t lo = vunc ? sn.c_lo : H2Y_GUARD_LO, span = vunc ? sn.c_span : H2Y_GUARD_SPAN;
+        const uint32_t db = fb - lo, dr = fr - lo;
+        guard = (db > dr ? db : dr) >= span;
+    } else {
+        /* YDzDx has no division, so without an unsure sample its chroma needs no guard at all */
+        guard = vunc & (((fb - sn.cb_lo) >= sn.cb_span) | ((fr - sn.cr_lo) >= sn.cr_span));
+    }
     return guard | (vunc & y_unsafe);
 }
 
@@ -807,6 +840,11 @@ inline bool t1_bounds(const pix_params &pp, t1_sens *sn)
     sn->cb_span = hiword_of(1.0 - Ecb) - sn->cb_lo;
     sn->cr_lo = hiword_of(Ecr) + 1;
     sn->cr_span = hiword_of(1.0 - Ecr) - sn->cr_lo;
+    {
+        const uint32_t hb = sn->cb_lo + sn->cb_span, hr = sn->cr_lo + sn->cr_span;
+        sn->c_lo = sn->cb_lo > sn->cr_lo ? sn->cb_lo : sn->cr_lo; /* safe region = intersection of the two */
+        sn->c_span = (hb < hr ? hb : hr) - sn->c_lo;
+    }
     /* ~10 % of pixels have an unsure sample; redo rate ~ 0.1 * 2 (Ey + Ecb + Ecr) must stay small */
     return (Ey + Ecb + Ecr) < 0.02;
 }
@@ -823,13 +861,26 @@ H2Y_FN float pix_scale(float v, float mul, float add)
 /* write_yuv per-sample step, tiff.cpp:469-478 (luma) / 502-511,533-543 (chroma).
  * lo/hi are minVR/maxVR (minVRC/maxVRC for chroma), or 0/maxCV when the output
  * is full range -- set up once in pix_params. */
+H2Y_FN uint32_t umed3(uint32_t v, uint32_t lo, uint32_t hi)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "s"(lo), "v"(hi));
+    return r;
+#else
+    return v < lo ? lo : (v > hi ? hi : v);
+#endif
+}
+/* Clamping the unshifted value to [lo << s, (hi << s) | (2^s - 1)] and shifting afterwards gives the
+ * same number as shifting first and clamping to [lo, hi]: one v_med3_u32 and one shift. */
 H2Y_FN uint32_t pix_yuv_clamp(const pix_params &pp, uint32_t v, bool chroma)
 {
-    v = v >> pp.down_shift;
-    const uint32_t lo = chroma ? pp.clo : pp.ylo, hi = chroma ? pp.chi : pp.yhi;
-    v = v < lo ? lo : v;
-    v = v > hi ? hi : v;
-    return v;
+    return umed3(v, chroma ? pp.clo_s : pp.ylo_s, chroma ? pp.chi_s : pp.yhi_s) >> pp.down_shift;
+}
+/* the 2x2 box: (a+b+c+d)/4 (convert.cpp:157-160, unsigned truncation), write_yuv's shift and clamp */
+H2Y_FN uint32_t pix_box_clamp(const pix_params &pp, uint32_t sum4)
+{
+    return umed3(sum4, pp.clo_b, pp.chi_b) >> (pp.down_shift + 2);
 }
 
 /* Subsample444to420_FIR stage 1, convert.cpp:305-317.  s[-5..5] around an

@@ -86,8 +86,8 @@ int main(int argc, char **argv)
                         if (wr++ < 3) fprintf(stderr, "T1 WRONG x=%a got %a want %a\n", x, got, want);
                     }
                     float c0h, ww;
-                    uint32_t off = pq_t1_offset((uint32_t)u) >> 4;
-                    if (off < H2Y_T1_NSEG) {
+                    uint32_t off = pq_t1_offset(x) >> 4;
+                    if (off >= 1 && off <= H2Y_T1_NSEG) {
                         pq_t1_parts((uint32_t)u, T1[off], &c0h, &ww);
                         double e = fabs(((double)c0h + (double)ww) - vref) / vref;
                         if (e > w) w = e;

@@ -276,7 +276,7 @@ fused_variant pick_variant(const h2y_desc *d, const pix_params &pp, int out_kind
         v.pipe = ident ? 1 : 2; /* 2 is always valid: (x - 0) / 1 == x exactly */
         if (pp.convert_transfer == 2) v.pipe = 0; /* generic transfer pair: runtime kernel, careful tier */
         /* binary32 first tier where few pixels would fall through it (moderate bit depths) */
-        if ((v.pipe == 1 || v.pipe == 2) && v.in_kind != H2Y_IN_U16 && t1_enabled() && t1_bounds(pp, sn)) v.pipe += 3;
+        if ((v.pipe == 1 || v.pipe == 2) && v.in_kind != H2Y_IN_U16 && (d->height & 1) == 0 && t1_enabled() && t1_bounds(pp, sn)) v.pipe += 3;
         /* half input with the identity normalisation: the whole transfer is a 64 KB table */
         if (ident && v.in_kind == H2Y_IN_F16 && (pp.mode == H2Y_MODE_YCBCR || pp.mode == H2Y_MODE_YDZDX)) v.pipe = 3;
     }
@@ -347,7 +347,7 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         a.patch_stride = 0;
         const bool patch = h2y_fused_needs_patch(var);
         if (patch) {
-            const size_t slots = ((size_t)g.tiles + 63) / 64;
+            const size_t slots = (size_t)g.chunks * waves; /* every wave of every chunk has one, also those past the frame's end */
             rc = ensure(ctx, ctx->d_patch, ctx->patch_cap, (size_t)nf * slots * sizeof(uint64_t));
             if (rc) return rc;
             a.patch_mask = ctx->d_patch;

@@ -380,6 +380,37 @@ __device__ __forceinline__ void tile_pack(const pix_params &pp, int jb, const ui
         o.crp0[jb] = Cr[0] | (Cr[1] << 16); o.crp1[jb] = Cr[2] | (Cr[3] << 16);
     }
 }
+/* the same packing one picture row (four pixels) at a time; sb/sr carry the 2x2 box sums from row 0 to row 1 */
+template <int OUT_KIND>
+__device__ __forceinline__ void row_pack(const pix_params &pp, int row, const uint32_t (&Y)[4], uint32_t (&Cb)[4], uint32_t (&Cr)[4],
+                                         tile_out &o, uint32_t (&sb)[2], uint32_t (&sr)[2])
+{
+    uint32_t(&yp)[2] = row ? o.yp1 : o.yp0;
+    yp[0] = pix_yuv_clamp(pp, Y[0], false) | (pix_yuv_clamp(pp, Y[1], false) << 16);
+    yp[1] = pix_yuv_clamp(pp, Y[2], false) | (pix_yuv_clamp(pp, Y[3], false) << 16);
+    if (OUT_KIND == H2Y_OUT_420BOX) {
+        if (row == 0) {
+            sb[0] = Cb[0] + Cb[1]; sb[1] = Cb[2] + Cb[3];
+            sr[0] = Cr[0] + Cr[1]; sr[1] = Cr[2] + Cr[3];
+        } else {
+            /* convert.cpp:157-160: (a+b+c+d)/4, unsigned truncation; then write_yuv's clamp */
+            o.cb_box = pix_box_clamp(pp, sb[0] + Cb[0] + Cb[1]) | (pix_box_clamp(pp, sb[1] + Cb[2] + Cb[3]) << 16);
+            o.cr_box = pix_box_clamp(pp, sr[0] + Cr[0] + Cr[1]) | (pix_box_clamp(pp, sr[1] + Cr[2] + Cr[3]) << 16);
+        }
+    } else {
+        if (OUT_KIND == H2Y_OUT_444) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                Cb[q] = pix_yuv_clamp(pp, Cb[q], true);
+                Cr[q] = pix_yuv_clamp(pp, Cr[q], true);
+            }
+        }
+        uint32_t(&cbp)[2] = row ? o.cbp1 : o.cbp0;
+        uint32_t(&crp)[2] = row ? o.crp1 : o.crp0;
+        cbp[0] = Cb[0] | (Cb[1] << 16); cbp[1] = Cb[2] | (Cb[3] << 16);
+        crp[0] = Cr[0] | (Cr[1] << 16); crp[1] = Cr[2] | (Cr[3] << 16);
+    }
+}
 template <int OUT_KIND>
 __device__ __forceinline__ void tile_store(const frame_io &io, const tile_pos &t, uint32_t W, uint32_t H, const tile_out &o)
 {
@@ -557,102 +588,101 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
     __syncthreads();
 
     const uint32_t W = a.width, H = a.height, G = gridDim.x;
-    /* The next tile's 96 bytes are requested before the current tile is worked on (the loop needs
-     * ~97 registers, the second tile_in fits under 128): with four waves per SIMD and one
-     * load-then-compute phase per tile, the memory latency was otherwise exposed. */
-    tile_in nxt;
-    bool have = false; /* nxt holds the tile this block meets next (uniform) */
+    /*
+     * Rolling prefetch.  A tile is worked on row by row (four pixels each); as soon as the last pixel
+     * of a row is done, that row's three 16-byte loads of the NEXT tile are issued into the registers
+     * just freed.  Each load is in flight for about half a tile's arithmetic, needs no second set of
+     * registers and no copies.
+     * The loop body has no branch and a fixed number of memory operations in a fixed order, so every
+     * wait is for exactly the loads it needs (memory operations complete in issue order; a store
+     * issued conditionally would have to be assumed absent, and its wait would swallow the loads
+     * behind it).  To that end:
+     *  - lanes past the end of a frame work on its last tile again and store the same bytes again;
+     *  - every lane stores the wave's redo mask to the wave's slot;
+     *  - the picture height is even (the host sends odd heights to k_fused).
+     */
+    tile_in v;         /* the tile being worked on; refilled row by row with the next one */
+    bool have = false; /* v holds the tile this block meets next (uniform) */
+    typedef in_traits<IN_KIND> IN;
     for (int f = 0; f < a.n_frames; f++) {
         const frame_io io = uniform_io(a.frames + f);
         const frame_io io_next = uniform_io(a.frames + (f + 1 < a.n_frames ? f + 1 : f)); /* for the prefetch across the frame boundary */
         mm6 mm;
         mm.reset();
-        /* results of the previous tile, stored at the top of the NEXT iteration: memory operations
-         * complete in issue order, so stores issued after the prefetch would make the wait for the
-         * prefetched tile a wait for them as well */
-        bool pend = false;
-        tile_out o_prev;
-        tile_pos t_prev;
-        uint64_t m_prev = 0;
-        uint32_t slot_prev = 0;
         const uint32_t gbase = (uint32_t)(((uint64_t)f * a.chunks_per_frame) % G);
         const uint32_t k_next_frame = (uint32_t)((blockIdx.x + G - (uint32_t)(((uint64_t)(f + 1) * a.chunks_per_frame) % G)) % G);
         uint32_t k = (blockIdx.x + G - gbase) % G;
         if (!have && k < a.chunks_per_frame) /* nothing on its way (first tile of the launch, or a block that skipped frames) */
-            tile_load<IN_KIND>(io, tile_locate(umin32(k * H2Y_T1_THREADS + threadIdx.x, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic), nxt);
+        {
+            tile_load<IN_KIND>(io, tile_locate(umin32(k * H2Y_T1_THREADS + threadIdx.x, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic), v);
+            /* have the data arrive here: entering the loop with these loads outstanding would make the
+             * loop's own waits (computed over both ways into it) wait for everything */
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                asm volatile("" ::"v"(v.g0[j]), "v"(v.b0[j]), "v"(v.r0[j]), "v"(v.g1[j]), "v"(v.b1[j]), "v"(v.r1[j]));
+        }
         for (; k < a.chunks_per_frame; k += G) {
             const uint32_t tt = k * H2Y_T1_THREADS + threadIdx.x;
-            const bool valid = tt < a.tiles_per_frame;
-            /* lanes past the end of the frame load its last tile again (no divergence around the loads) */
-            const tile_pos t = tile_locate(umin32(tt, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
-            const tile_in v = nxt;
-            if (pend) {
-                tile_store<OUT_KIND>(io, t_prev, W, H, o_prev);
-                if ((threadIdx.x & (WAVE - 1)) == 0) a.patch_mask[(size_t)f * a.patch_stride + slot_prev] = m_prev;
-            }
-            pend = valid;
-            {
-                /* Where does this block go next: k + G in this frame, else its first chunk of the next
-                 * frame.  The request is unconditional (a branch around it makes the compiler wait for the
-                 * data on the spot): when there is no next tile, this tile is simply asked for again. */
-                uint32_t k2 = k + G;
-                const bool same = k2 < a.chunks_per_frame;
-                if (!same) k2 = k_next_frame;
-                have = same || (f + 1 < a.n_frames && k2 < a.chunks_per_frame);
-                if (!have) k2 = k;
-                const uint32_t tt2 = umin32(k2 * H2Y_T1_THREADS + threadIdx.x, a.tiles_per_frame - 1u);
-                const tile_pos t2 = tile_locate(tt2, W, H, a.wq, a.wq_magic);
-                frame_io src = io;
-                if (!same && have) {
+            tile_pos t = tile_locate(umin32(tt, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
+            t.row1 = true;
+            /* Where does this block go next: k + G in this frame, else its first chunk of the next frame.
+             * When there is no next tile, this tile is simply asked for again. */
+            uint32_t k2 = k + G;
+            const bool same = k2 < a.chunks_per_frame;
+            if (!same) k2 = k_next_frame;
+            have = same || (f + 1 < a.n_frames && k2 < a.chunks_per_frame);
+            if (!have) k2 = k;
+            const tile_pos t2 = tile_locate(umin32(k2 * H2Y_T1_THREADS + threadIdx.x, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
+            const void *src[3];
 #pragma unroll
-                    for (int c = 0; c < 3; c++) src.in[c] = io_next.in[c];
-                }
-                tile_load<IN_KIND>(src, t2, nxt);
-            }
-            if (!valid) continue;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                mm.add2(0, v.g0[j], v.g1[j]);
-                mm.add2(1, v.b0[j], v.b1[j]);
-                mm.add2(2, v.r0[j], v.r1[j]);
-            }
+            for (int c = 0; c < 3; c++) src[c] = (!same && have) ? io_next.in[c] : io.in[c];
+
             tile_out o;
+            uint32_t sb[2], sr[2]; /* 2x2 box: chroma sums of the two blocks */
             uint32_t redo_n = 0;
 #pragma unroll
-            for (int jb = 0; jb < 2; jb++) {
+            for (int row = 0; row < 2; row++) {
+                const float(&gv)[4] = row ? v.g1 : v.g0;
+                const float(&bv)[4] = row ? v.b1 : v.b0;
+                const float(&rv)[4] = row ? v.r1 : v.r0;
+                mm.add2(0, gv[0], gv[1]); mm.add2(0, gv[2], gv[3]);
+                mm.add2(1, bv[0], bv[1]); mm.add2(1, bv[2], bv[3]);
+                mm.add2(2, rv[0], rv[1]); mm.add2(2, rv[2], rv[3]);
                 uint32_t Y[4], Cb[4], Cr[4];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int col = 2 * jb + (q & 1);
-                    const float Gn = norm1<PIPE>(pp, 0, q < 2 ? v.g0[col] : v.g1[col]);
-                    const float Bn = norm1<PIPE>(pp, 1, q < 2 ? v.b0[col] : v.b1[col]);
-                    const float Rn = norm1<PIPE>(pp, 2, q < 2 ? v.r0[col] : v.r1[col]);
+                for (int col = 0; col < 4; col++) {
+                    const float Gn = norm1<PIPE>(pp, 0, gv[col]);
+                    const float Bn = norm1<PIPE>(pp, 1, bv[col]);
+                    const float Rn = norm1<PIPE>(pp, 2, rv[col]);
                     bool ug, ub, ur;
                     const float g = pix_scale(pq_t1(Gn, s_t1, &ug), pp.mulY, pp.addY);
                     const float b = pix_scale(pq_t1(Bn, s_t1, &ub), pp.mulC, pp.addC);
                     const float r = pix_scale(pq_t1(Rn, s_t1, &ur), pp.mulC, pp.addC);
-                    redo_n += pix_matrix_t1<MODE>(pp, sn, g, b, r, ug | ub | ur, Y[q], Cb[q], Cr[q]) ? 1u : 0u;
+                    redo_n += pix_matrix_t1<MODE>(pp, sn, g, b, r, ug | ub | ur, Y[col], Cb[col], Cr[col]) ? 1u : 0u;
                     /* pin the count here: left alone, the compiler postpones every pixel's guard arithmetic
                      * to the end of the tile and keeps its operands alive until then (register spills) */
                     asm volatile("" : "+v"(redo_n));
-#if H2Y_T1_SCHED_GROUP
-                    /* keep the scheduler from interleaving all eight pixels (it runs out of registers) */
-                    if ((q % H2Y_T1_SCHED_GROUP) == H2Y_T1_SCHED_GROUP - 1) __builtin_amdgcn_sched_barrier(0);
-#endif
                 }
-                tile_pack<OUT_KIND>(pp, jb, Y, Cb, Cr, o);
+                row_pack<OUT_KIND>(pp, row, Y, Cb, Cr, o, sb, sr);
+                if (row == 0) { /* row 0 of the next tile, into the registers just read for the last time */
+                    IN::load4(src[0], t2.i0, v.g0);
+                    IN::load4(src[1], t2.i0, v.b0);
+                    IN::load4(src[2], t2.i0, v.r0);
+                    /* nothing of row 1 may move up past this point: its data is the youngest request */
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
+            tile_store<OUT_KIND>(io, t, W, H, o);
             /* tiles to redo (a few lanes of about one wave in four at 12 bits; whole waves on black bars):
-             * every wave leaves its 64-bit lane mask, zero or not, in its own slot -- no atomics, no
+             * the wave's 64-bit lane mask, zero or not, goes to the wave's own slot -- no atomics, no
              * counters.  tt = 64 * slot + lane. */
-            o_prev = o;
-            t_prev = t;
-            m_prev = __ballot(redo_n != 0);
-            slot_prev = tt / WAVE;
-        }
-        if (pend) {
-            tile_store<OUT_KIND>(io, t_prev, W, H, o_prev);
-            if ((threadIdx.x & (WAVE - 1)) == 0) a.patch_mask[(size_t)f * a.patch_stride + slot_prev] = m_prev;
+            {
+                const uint64_t m = __ballot(tt < a.tiles_per_frame && redo_n != 0);
+                gstore<uint64_t>(a.patch_mask, (uint32_t)f * a.patch_stride + tt / WAVE, m);
+            }
+            IN::load4(src[0], t2.i1, v.g1);
+            IN::load4(src[1], t2.i1, v.b1);
+            IN::load4(src[2], t2.i1, v.r1);
         }
         wave_store_mm(mm, a.partial + (((size_t)f * G + blockIdx.x) * (H2Y_T1_THREADS / WAVE) + threadIdx.x / WAVE) * 6);
     }
@@ -674,7 +704,7 @@ __global__ __launch_bounds__(H2Y_PATCH_THREADS) void k_patch(fused_args a)
     const pix_params pp = with_assumed(a.pp, a.assumed);
     if (threadIdx.x == 0) s_pp = pp;
     const int f = blockIdx.y;
-    const uint32_t n_slots = (a.tiles_per_frame + WAVE - 1) / WAVE;
+    const uint32_t n_slots = (a.tiles_per_frame + WAVE - 1) / WAVE; /* slots past it exist (whole waves past the frame's end) and hold 0 */
     const uint32_t slot = blockIdx.x * H2Y_PATCH_THREADS + threadIdx.x;
     const uint64_t m = slot < n_slots ? a.patch_mask[(size_t)f * a.patch_stride + slot] : 0ull;
     const uint32_t lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;

@@ -531,7 +531,18 @@ H2Y_FN uint32_t pq_t1_offset(float x)
 H2Y_FN float pq_t1(float x, const pq_rec1 *__restrict__ T, bool *unsure)
 {
     const uint32_t bits = f2bits(x);
+#if defined(__HIP_DEVICE_COMPILE__)
+    /* T is in LDS.  Address = (index << 4) + (table - first index * 16) as ONE v_lshl_add_u32; written
+     * out because the compiler prefers shift-right 11, and-not 15, add. */
+    typedef const __attribute__((address_space(3))) pq_rec1 *lds_rec;
+    const uint32_t tbase = (uint32_t)(uintptr_t)(lds_rec)T - ((H2Y_T1_BASE - 1u) << 4);
+    const uint32_t seg = f2bits(__builtin_amdgcn_fmed3f(x, bits2f(H2Y_T1_LO_SENTINEL_BITS), 2.0f)) >> H2Y_T1_LOW_BITS;
+    uint32_t addr;
+    asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(addr) : "v"(seg), "s"(tbase));
+    const pq_rec1 r = *(lds_rec)(uintptr_t)addr;
+#else
     const pq_rec1 r = *reinterpret_cast<const pq_rec1 *>(reinterpret_cast<const char *>(T) + pq_t1_offset(x));
+#endif
     float c0h, w;
     pq_t1_parts(bits, r, &c0h, &w);
     const float s = c0h + w;

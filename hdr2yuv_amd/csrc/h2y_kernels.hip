@@ -602,6 +602,7 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
      *  - the picture height is even (the host sends odd heights to k_fused).
      */
     tile_in v;         /* the tile being worked on; refilled row by row with the next one */
+    tile_pos t_cur;    /* and where it is */
     bool have = false; /* v holds the tile this block meets next (uniform) */
     typedef in_traits<IN_KIND> IN;
     for (int f = 0; f < a.n_frames; f++) {
@@ -614,7 +615,8 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
         uint32_t k = (blockIdx.x + G - gbase) % G;
         if (!have && k < a.chunks_per_frame) /* nothing on its way (first tile of the launch, or a block that skipped frames) */
         {
-            tile_load<IN_KIND>(io, tile_locate(umin32(k * H2Y_T1_THREADS + threadIdx.x, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic), v);
+            t_cur = tile_locate(umin32(k * H2Y_T1_THREADS + threadIdx.x, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
+            tile_load<IN_KIND>(io, t_cur, v);
             /* have the data arrive here: entering the loop with these loads outstanding would make the
              * loop's own waits (computed over both ways into it) wait for everything */
 #pragma unroll
@@ -623,7 +625,7 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
         }
         for (; k < a.chunks_per_frame; k += G) {
             const uint32_t tt = k * H2Y_T1_THREADS + threadIdx.x;
-            tile_pos t = tile_locate(umin32(tt, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
+            tile_pos t = t_cur; /* located one iteration ago, as the prefetch target */
             t.row1 = true;
             /* Where does this block go next: k + G in this frame, else its first chunk of the next frame.
              * When there is no next tile, this tile is simply asked for again. */
@@ -683,6 +685,7 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
             IN::load4(src[0], t2.i1, v.g1);
             IN::load4(src[1], t2.i1, v.b1);
             IN::load4(src[2], t2.i1, v.r1);
+            t_cur = t2;
         }
         wave_store_mm(mm, a.partial + (((size_t)f * G + blockIdx.x) * (H2Y_T1_THREADS / WAVE) + threadIdx.x / WAVE) * 6);
     }

@@ -504,7 +504,7 @@ inline void pq_build_table(pq_recA *A, pq_recB *B)
 struct alignas(16) pq_rec1 {
     float c0h, c0l, c1, c2;
 };
-/* the real-number value of the T1 evaluation, as (c0h, w); shared with tools */
+/* the real-number value of the T1 evaluation, as (c0h, 2^25 w); shared with tools */
 H2Y_FN void pq_t1_parts(uint32_t bits, const pq_rec1 &r, float *c0h, float *w)
 {
     float f = bits2f((bits & ((1u << H2Y_T1_LOW_BITS) - 1u)) | 0x3F800000u);
@@ -543,14 +543,15 @@ H2Y_FN float pq_t1(float x, const pq_rec1 *__restrict__ T, bool *unsure)
 #else
     const pq_rec1 r = *reinterpret_cast<const pq_rec1 *>(reinterpret_cast<const char *>(T) + pq_t1_offset(x));
 #endif
-    float c0h, w;
-    pq_t1_parts(bits, r, &c0h, &w);
-    const float s = c0h + w;
-    const float e = w - (s - c0h); /* exact: |c0h| >= |w| */
-    /* ulp(s)/2 - delta with delta = RELERR*s <= RELERR * 2^25 * ulp(s)/2: one constant factor
-     * (1 - RELERR*2^25) of ulp(s)/2, built from s's exponent and that factor's mantissa */
-    const float thr = bits2f(((f2bits(s) & 0x7F800000u) | H2Y_T1_THR_MANT) - (25u << 23));
-    *unsure = !(__builtin_fabsf(e) < thr); /* NaN (sentinel record) => unsure */
+    float c0h, ws; /* ws = 2^25 w: the table holds c0l, c1, c2 times 2^25 (exact scaling) */
+    pq_t1_parts(bits, r, &c0h, &ws);
+    const float s = __builtin_fmaf(ws, 0x1p-25f, c0h);       /* RN(c0h + w) */
+    const float es = __builtin_fmaf(s - c0h, -0x1p25f, ws);  /* 2^25 (w - (s - c0h)), exact: |c0h| >= |w| */
+    /* |e| against ulp(s)/2 - delta with delta = RELERR*s <= RELERR * 2^25 * ulp(s)/2: one constant factor
+     * (1 - RELERR*2^25) of ulp(s)/2; times 2^25 that is s's exponent with that factor's mantissa
+     * (1.98...), which v_and_or_b32 builds in one instruction -- hence the scaled w */
+    const float thr = bits2f((f2bits(s) & 0x7F800000u) | H2Y_T1_THR_MANT);
+    *unsure = !(__builtin_fabsf(es) < thr); /* NaN (sentinel record) => unsure */
     return s;
 }
 inline void pq_build_table1(pq_rec1 *T)
@@ -576,9 +577,9 @@ inline void pq_build_table1(pq_rec1 *T)
         const double r = (double)(2 << H2Y_T1_SEG_BITS);
         pq_rec1 &o = T[i + 1]; /* record 0 is the low sentinel */
         o.c0h = (float)q0.hi;
-        o.c0l = (float)((q0.hi - (double)o.c0h) + q0.lo);
-        o.c1 = (float)(q1.hi * r);
-        o.c2 = (float)(q2.hi * r * r);
+        o.c0l = (float)((q0.hi - (double)o.c0h) + q0.lo) * 0x1p25f; /* the three below c0h carry a factor 2^25, see pq_t1() */
+        o.c1 = (float)(q1.hi * r) * 0x1p25f;
+        o.c2 = (float)(q2.hi * r * r) * 0x1p25f;
     }
     for (int i = 0; i < 2; i++) {
         pq_rec1 &o = T[i ? H2Y_T1_NSEG + 1 : 0];

@@ -89,7 +89,7 @@ int main(int argc, char **argv)
                     uint32_t off = pq_t1_offset(x) >> 4;
                     if (off >= 1 && off <= H2Y_T1_NSEG) {
                         pq_t1_parts((uint32_t)u, T1[off], &c0h, &ww);
-                        double e = fabs(((double)c0h + (double)ww) - vref) / vref;
+                        double e = fabs(((double)c0h + (double)ww * 0x1p-25) - vref) / vref;
                         if (e > w) w = e;
                     }
                 }

@@ -72,8 +72,6 @@ struct h2y_ctx {
     frame_io *d_frames = nullptr, *h_frames = nullptr;
     size_t frames_cap = 0;
     float *d_partial = nullptr;
-    uint64_t *d_patch = nullptr; /* k_fused_t1 -> k_patch: one lane mask per wave-tile of every frame of a launch */
-    size_t patch_cap = 0;
     size_t partial_cap = 0;
     frame_stats *d_fstats = nullptr, *h_fstats = nullptr;
     size_t fstats_cap = 0;
@@ -297,7 +295,9 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
     derive_params(d, &pp, false);
     const int out_kind = out_kind_of(d);
     t1_sens sn;
-    const fused_variant var = pick_variant(d, pp, out_kind, known, &sn);
+    fused_variant var = pick_variant(d, pp, out_kind, known, &sn);
+    /* k_fused_t1's redo list numbers tiles as frame * tiles + tile in 32 bits */
+    if ((var.pipe == 4 || var.pipe == 5) && (uint64_t)n * make_geom(d, h2y_fused_threads(var)).tiles >= 0xFFFFFFFFull) var.pipe -= 3;
     const geom g = make_geom(d, h2y_fused_threads(var));
     const size_t npix = (size_t)d->width * d->height;
     const int step = out_kind == H2Y_OUT_444TMP ? kFirSubBatch : n;
@@ -343,16 +343,7 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         a.partial = ctx->d_partial;
         a.assumed = d_assumed;
         a.pp = pp;
-        a.patch_mask = nullptr;
-        a.patch_stride = 0;
-        const bool patch = h2y_fused_needs_patch(var);
-        if (patch) {
-            const size_t slots = (size_t)g.chunks * waves; /* every wave of every chunk has one, also those past the frame's end */
-            rc = ensure(ctx, ctx->d_patch, ctx->patch_cap, (size_t)nf * slots * sizeof(uint64_t));
-            if (rc) return rc;
-            a.patch_mask = ctx->d_patch;
-            a.patch_stride = (uint32_t)slots;
-        }
+        a.tiles_magic = g.tiles > 1 ? (uint32_t)(0x100000000ull / g.tiles) : 0xFFFFFFFFu;
         const bool ev = time_it && ctx->n_ev < kMaxEvents;
         if (ev) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->n_ev][0], ctx->stream));
@@ -363,7 +354,6 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
             HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->n_ev][1], ctx->stream));
             ctx->n_ev++;
         }
-        if (patch) HIP_TRY(ctx, h2y_launch_patch(var, ctx->stream, a));
         final_args fa;
         fa.partial = ctx->d_partial;
         fa.nblk = grid * waves;
@@ -585,7 +575,6 @@ void h2y_ctx_destroy(h2y_ctx *ctx)
     (void)hipFree(ctx->d_frames);
     (void)hipHostFree(ctx->h_frames);
     (void)hipFree(ctx->d_partial);
-    (void)hipFree(ctx->d_patch);
     (void)hipFree(ctx->d_fstats);
     (void)hipHostFree(ctx->h_fstats);
     (void)hipFree(ctx->d_assumed);
@@ -849,8 +838,7 @@ int h2y_matrix_convert(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3
     a.lut16 = ctx->d_lut16;
     a.table1 = ctx->d_table1;
     memset(&a.sn, 0, sizeof a.sn);
-    a.patch_mask = nullptr;
-    a.patch_stride = 0;
+    a.tiles_magic = 0;
     a.partial = ctx->d_partial;
     a.assumed = ctx->d_assumed;
     a.pp = pp;

@@ -57,11 +57,7 @@ struct fused_args {
     const float *lut16;       /* k_fused_lut16: PQ of every half in [0,2) */
     const void *table1;       /* k_fused_t1: pq_rec1[H2Y_T1_NREC] */
     h2y::t1_sens sn;          /* k_fused_t1: sensitivity windows */
-    /* k_fused_t1 -> k_patch: which tiles to redo exactly.  One 64-bit lane mask per wave and chunk:
-     * bit l of patch_mask[frame][s] is thread-tile 64 s + l.  Every slot below ceil(tiles/64) is
-     * written by every launch (no initialisation needed). */
-    uint64_t *patch_mask;
-    uint32_t patch_stride;    /* slots per frame */
+    uint32_t tiles_magic;     /* floor(2^32 / tiles_per_frame): k_fused_t1's redo list holds frame * tiles + tile */
     float *partial;           /* [n_frames][grid][6] */
     const assumed_stats *assumed;
     h2y::pix_params pp;       /* offset/range/norm_identity are filled in-kernel from *assumed */
@@ -108,8 +104,6 @@ int h2y_fused_threads(const fused_variant &v);
 const char *h2y_fused_name(const fused_variant &v);
 int h2y_fused_blocks_per_cu(const fused_variant &v);
 hipError_t h2y_launch_fused(const fused_variant &v, int grid, hipStream_t st, const fused_args &a);
-bool h2y_fused_needs_patch(const fused_variant &v);
-hipError_t h2y_launch_patch(const fused_variant &v, hipStream_t st, const fused_args &a);
 hipError_t h2y_launch_build_lut16(hipStream_t st, const void *table, float *lut);
 hipError_t h2y_launch_stats(int in_kind, int grid, hipStream_t st, const stats_args &a);
 hipError_t h2y_launch_stats_final(int n_frames, hipStream_t st, const final_args &a);

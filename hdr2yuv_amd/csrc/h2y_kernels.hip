@@ -546,59 +546,89 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
 }
 
 /*
- * k_fused_t1: the same work with a binary32 FIRST TIER in front (PQ output,
- * YCbCr or YDzDx, bit depths where t1_bounds() says it pays).
+ * k_fused_t1: the same work with a binary32 FIRST TIER in front (LINEAR -> PQ, YCbCr or YDzDx,
+ * float input, even height).
  *
- *   tier 1  pq_t1(): one 16-byte LDS record and ~16 binary32 instructions per
- *           sample give the reference's float for 99 % of samples and say so;
- *           the matrix step is the exact one (pix_matrix_t1).  A pixel is final
- *           unless one of its samples was "unsure" AND one of its three integers
- *           could change with a one-ulp change of that sample (0.05 % of pixels
- *           at 12 bits), or the reciprocal-division guard fires.  The hot loop has
- *           no branch for them: a tile holding such a pixel is appended to a per-
- *           frame list (one atomic) and k_patch, a small second kernel, redoes the
- *           listed tiles with
- *   tier 2  pixel_fast<>() -- the binary64 polynomial, table from HBM/L2 -- and
- *   tier 3  pixel_careful(), as k_fused does.
- *   Tiles with a sample outside the T1 table (+0.0 above all: black bars) are
- *   common in real pictures, so they do not go to the list: the tile-local
- *   min/max (already needed for pic_stats) sends the whole tile through tiers
- *   2/3 at once, out of line (tile_t23).
+ *   tier 1  pq_t1(): one 16-byte LDS record and ~15 binary32 instructions per sample give the
+ *           reference's float for 99 % of samples and say so; the matrix step is the exact one
+ *           (pix_matrix_t1).  A pixel is final unless one of its samples was "unsure" AND one of
+ *           its three integers could change with a one-ulp change of that sample (0.05 % of pixels
+ *           at 12 bits, 0.8 % at 16), or the reciprocal-division guard fires, or a sample lies
+ *           outside the table (+0.0 above all: black bars).
+ *   The tile loop has no branch for such pixels.  The lanes whose tile holds one append the tile's
+ *   number to their wave's list in LDS; when a wave has 64 of them it leaves the loop, redoes those
+ *   64 tiles -- one per lane, all lanes busy -- with
+ *   tier 2  pixel_fast<>(), the binary64 polynomial (its table is in LDS too), and
+ *   tier 3  pixel_careful(), exactly as k_fused does (redo_pass), stores them over T1's
+ *           provisional bytes and re-enters the loop.  No second kernel, no atomics.
  *
- * 1024 threads per block, one block per CU: the T1 table (256 segments per
- * binade) takes 100 KB of LDS.
+ * 1024 threads per block, one block per CU: 100 KB (T1 table) + 50 KB (binary64 table) + 8 KB
+ * (sixteen wave lists) of the CU's 160 KB of LDS.
  */
 #define H2Y_T1_THREADS 1024
-#ifndef H2Y_T1_SCHED_GROUP
-#define H2Y_T1_SCHED_GROUP 0 /* >0: scheduling barrier after every so many pixels of k_fused_t1's tile loop */
-#endif
+#define H2Y_REDO_CAP 128 /* list entries per wave: up to 63 left over plus the 64 one tile can add */
+struct redo_ctx {        /* what redo_pass needs, handed over in LDS so that the call carries two pointers */
+    const frame_io *frames;
+    uint32_t width, height, wq, wq_magic, tiles_per_frame, tiles_magic;
+};
+/* one tile per lane out of the wave's list: entries [first, first + cnt) */
+template <int IN_KIND, int OUT_KIND, int MODE, int PIPE>
+__device__ __forceinline__ void redo_pass(const redo_ctx *rc, const pix_params *spp, const pq_recA *sA, const uint32_t *list,
+                                                    uint32_t first, uint32_t cnt)
+{
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    if (lane >= cnt) return;
+    const pq_recB *sB = reinterpret_cast<const pq_recB *>(sA + H2Y_PQ_NREC);
+    uint32_t tt;
+    const uint32_t f = udiv_magic(list[first + lane], rc->tiles_per_frame, rc->tiles_magic, tt); /* entry = frame * tiles + tile */
+    const frame_io io = rc->frames[f]; /* differs from lane to lane */
+    const tile_pos t = tile_locate(tt, rc->width, rc->height, rc->wq, rc->wq_magic);
+    tile_in v;
+    tile_load<IN_KIND>(io, t, v);
+    tile_out o;
+    tile_exact<OUT_KIND, MODE, PIPE>(*spp, spp, sA, sB, v, o);
+    tile_store<OUT_KIND>(io, t, rc->width, rc->height, o);
+}
+
 template <int IN_KIND, int OUT_KIND, int MODE, int PIPE>
 __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
 {
     __shared__ pq_rec1 s_t1[H2Y_T1_NREC];
+    __shared__ pq_recA s_t2[2 * H2Y_PQ_NREC]; /* A records, then B records */
+    __shared__ uint32_t s_redo[H2Y_T1_THREADS / WAVE][H2Y_REDO_CAP];
     __shared__ pix_params s_pp;
+    __shared__ redo_ctx s_rc;
     {
         const uint4 *g = reinterpret_cast<const uint4 *>(a.table1);
         uint4 *l = reinterpret_cast<uint4 *>(s_t1);
         for (int i = threadIdx.x; i < H2Y_T1_NREC; i += H2Y_T1_THREADS) l[i] = g[i];
+        stage_table<H2Y_T1_THREADS>(a.table, s_t2);
     }
     const pix_params pp = with_assumed(a.pp, a.assumed);
     const t1_sens sn = a.sn;
-    if (threadIdx.x == 0) s_pp = pp;
+    if (threadIdx.x == 0) {
+        s_pp = pp;
+        s_rc.frames = a.frames;
+        s_rc.width = a.width; s_rc.height = a.height; s_rc.wq = a.wq; s_rc.wq_magic = a.wq_magic;
+        s_rc.tiles_per_frame = a.tiles_per_frame; s_rc.tiles_magic = a.tiles_magic;
+    }
     __syncthreads();
 
     const uint32_t W = a.width, H = a.height, G = gridDim.x;
+    const uint32_t lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    uint32_t *const my_list = s_redo[wave];
+    uint32_t n_redo = 0; /* entries in my_list (uniform over the wave) */
     /*
      * Rolling prefetch.  A tile is worked on row by row (four pixels each); as soon as the last pixel
      * of a row is done, that row's three 16-byte loads of the NEXT tile are issued into the registers
      * just freed.  Each load is in flight for about half a tile's arithmetic, needs no second set of
      * registers and no copies.
-     * The loop body has no branch and a fixed number of memory operations in a fixed order, so every
-     * wait is for exactly the loads it needs (memory operations complete in issue order; a store
-     * issued conditionally would have to be assumed absent, and its wait would swallow the loads
-     * behind it).  To that end:
+     * The loop body is one basic block with a fixed number of memory operations in a fixed order, so
+     * every wait is for exactly the loads it needs (memory operations complete in issue order; a
+     * store issued conditionally would have to be assumed absent, and its wait would swallow the
+     * loads behind it).  To that end:
      *  - lanes past the end of a frame work on its last tile again and store the same bytes again;
-     *  - every lane stores the wave's redo mask to the wave's slot;
+     *  - the redo list is appended to with LDS writes only, and working it off happens outside the loop;
      *  - the picture height is even (the host sends odd heights to k_fused).
      */
     tile_in v;         /* the tile being worked on; refilled row by row with the next one */
@@ -612,136 +642,95 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
         mm.reset();
         const uint32_t gbase = (uint32_t)(((uint64_t)f * a.chunks_per_frame) % G);
         const uint32_t k_next_frame = (uint32_t)((blockIdx.x + G - (uint32_t)(((uint64_t)(f + 1) * a.chunks_per_frame) % G)) % G);
+        const uint32_t id_base = (uint32_t)f * a.tiles_per_frame;
         uint32_t k = (blockIdx.x + G - gbase) % G;
-        if (!have && k < a.chunks_per_frame) /* nothing on its way (first tile of the launch, or a block that skipped frames) */
-        {
-            t_cur = tile_locate(umin32(k * H2Y_T1_THREADS + threadIdx.x, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
-            tile_load<IN_KIND>(io, t_cur, v);
-            /* have the data arrive here: entering the loop with these loads outstanding would make the
-             * loop's own waits (computed over both ways into it) wait for everything */
+        while (k < a.chunks_per_frame) {
+            if (!have) { /* nothing on its way (first tile of the launch, or a block that skipped frames) */
+                t_cur = tile_locate(umin32(k * H2Y_T1_THREADS + threadIdx.x, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
+                tile_load<IN_KIND>(io, t_cur, v);
+            }
+            /* have the data arrive here: entering the loop with loads outstanding would make the loop's
+             * own waits (computed over all ways into it) wait for everything */
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 asm volatile("" ::"v"(v.g0[j]), "v"(v.b0[j]), "v"(v.r0[j]), "v"(v.g1[j]), "v"(v.b1[j]), "v"(v.r1[j]));
-        }
-        for (; k < a.chunks_per_frame; k += G) {
-            const uint32_t tt = k * H2Y_T1_THREADS + threadIdx.x;
-            tile_pos t = t_cur; /* located one iteration ago, as the prefetch target */
-            t.row1 = true;
-            /* Where does this block go next: k + G in this frame, else its first chunk of the next frame.
-             * When there is no next tile, this tile is simply asked for again. */
-            uint32_t k2 = k + G;
-            const bool same = k2 < a.chunks_per_frame;
-            if (!same) k2 = k_next_frame;
-            have = same || (f + 1 < a.n_frames && k2 < a.chunks_per_frame);
-            if (!have) k2 = k;
-            const tile_pos t2 = tile_locate(umin32(k2 * H2Y_T1_THREADS + threadIdx.x, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
-            const void *src[3];
+            for (; k < a.chunks_per_frame && n_redo < WAVE; k += G) {
+                const uint32_t tt = k * H2Y_T1_THREADS + threadIdx.x;
+                tile_pos t = t_cur; /* located one iteration ago, as the prefetch target */
+                t.row1 = true;
+                /* Where does this block go next: k + G in this frame, else its first chunk of the next frame.
+                 * When there is no next tile, this tile is simply asked for again. */
+                uint32_t k2 = k + G;
+                const bool same = k2 < a.chunks_per_frame;
+                if (!same) k2 = k_next_frame;
+                have = same || (f + 1 < a.n_frames && k2 < a.chunks_per_frame);
+                if (!have) k2 = k;
+                const tile_pos t2 = tile_locate(umin32(k2 * H2Y_T1_THREADS + threadIdx.x, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
+                const void *src[3];
 #pragma unroll
-            for (int c = 0; c < 3; c++) src[c] = (!same && have) ? io_next.in[c] : io.in[c];
+                for (int c = 0; c < 3; c++) src[c] = (!same && have) ? io_next.in[c] : io.in[c];
 
-            tile_out o;
-            uint32_t sb[2], sr[2]; /* 2x2 box: chroma sums of the two blocks */
-            uint32_t redo_n = 0;
+                tile_out o;
+                uint32_t sb[2], sr[2]; /* 2x2 box: chroma sums of the two blocks */
+                uint32_t redo_n = 0;
 #pragma unroll
-            for (int row = 0; row < 2; row++) {
-                const float(&gv)[4] = row ? v.g1 : v.g0;
-                const float(&bv)[4] = row ? v.b1 : v.b0;
-                const float(&rv)[4] = row ? v.r1 : v.r0;
-                mm.add2(0, gv[0], gv[1]); mm.add2(0, gv[2], gv[3]);
-                mm.add2(1, bv[0], bv[1]); mm.add2(1, bv[2], bv[3]);
-                mm.add2(2, rv[0], rv[1]); mm.add2(2, rv[2], rv[3]);
-                uint32_t Y[4], Cb[4], Cr[4];
+                for (int row = 0; row < 2; row++) {
+                    const float(&gv)[4] = row ? v.g1 : v.g0;
+                    const float(&bv)[4] = row ? v.b1 : v.b0;
+                    const float(&rv)[4] = row ? v.r1 : v.r0;
+                    mm.add2(0, gv[0], gv[1]); mm.add2(0, gv[2], gv[3]);
+                    mm.add2(1, bv[0], bv[1]); mm.add2(1, bv[2], bv[3]);
+                    mm.add2(2, rv[0], rv[1]); mm.add2(2, rv[2], rv[3]);
+                    uint32_t Y[4], Cb[4], Cr[4];
 #pragma unroll
-                for (int col = 0; col < 4; col++) {
-                    const float Gn = norm1<PIPE>(pp, 0, gv[col]);
-                    const float Bn = norm1<PIPE>(pp, 1, bv[col]);
-                    const float Rn = norm1<PIPE>(pp, 2, rv[col]);
-                    bool ug, ub, ur;
-                    const float g = pix_scale(pq_t1(Gn, s_t1, &ug), pp.mulY, pp.addY);
-                    const float b = pix_scale(pq_t1(Bn, s_t1, &ub), pp.mulC, pp.addC);
-                    const float r = pix_scale(pq_t1(Rn, s_t1, &ur), pp.mulC, pp.addC);
-                    redo_n += pix_matrix_t1<MODE>(pp, sn, g, b, r, ug | ub | ur, Y[col], Cb[col], Cr[col]) ? 1u : 0u;
-                    /* pin the count here: left alone, the compiler postpones every pixel's guard arithmetic
-                     * to the end of the tile and keeps its operands alive until then (register spills) */
-                    asm volatile("" : "+v"(redo_n));
+                    for (int col = 0; col < 4; col++) {
+                        const float Gn = norm1<PIPE>(pp, 0, gv[col]);
+                        const float Bn = norm1<PIPE>(pp, 1, bv[col]);
+                        const float Rn = norm1<PIPE>(pp, 2, rv[col]);
+                        bool ug, ub, ur;
+                        const float g = pix_scale(pq_t1(Gn, s_t1, &ug), pp.mulY, pp.addY);
+                        const float b = pix_scale(pq_t1(Bn, s_t1, &ub), pp.mulC, pp.addC);
+                        const float r = pix_scale(pq_t1(Rn, s_t1, &ur), pp.mulC, pp.addC);
+                        redo_n += pix_matrix_t1<MODE>(pp, sn, g, b, r, ug | ub | ur, Y[col], Cb[col], Cr[col]) ? 1u : 0u;
+                        /* pin the count here: left alone, the compiler postpones every pixel's guard arithmetic
+                         * to the end of the tile and keeps its operands alive until then (register spills) */
+                        asm volatile("" : "+v"(redo_n));
+                    }
+                    row_pack<OUT_KIND>(pp, row, Y, Cb, Cr, o, sb, sr);
+                    if (row == 0) { /* row 0 of the next tile, into the registers just read for the last time */
+                        IN::load4(src[0], t2.i0, v.g0);
+                        IN::load4(src[1], t2.i0, v.b0);
+                        IN::load4(src[2], t2.i0, v.r0);
+                        /* nothing of row 1 may move up past this point: its data is the youngest request */
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
                 }
-                row_pack<OUT_KIND>(pp, row, Y, Cb, Cr, o, sb, sr);
-                if (row == 0) { /* row 0 of the next tile, into the registers just read for the last time */
-                    IN::load4(src[0], t2.i0, v.g0);
-                    IN::load4(src[1], t2.i0, v.b0);
-                    IN::load4(src[2], t2.i0, v.r0);
-                    /* nothing of row 1 may move up past this point: its data is the youngest request */
-                    __builtin_amdgcn_sched_barrier(0);
+                tile_store<OUT_KIND>(io, t, W, H, o);
+                IN::load4(src[0], t2.i1, v.g1);
+                IN::load4(src[1], t2.i1, v.b1);
+                IN::load4(src[2], t2.i1, v.r1);
+                t_cur = t2;
+                /* tiles to redo (a few lanes of about one wave in four at 12 bits; whole waves on black
+                 * bars) go to the wave's list: position = entries so far + flagged lanes below this one */
+                {
+                    const bool flagged = tt < a.tiles_per_frame && redo_n != 0;
+                    const uint64_t m = __ballot(flagged);
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    /* unflagged lanes write to the spare last slot: no branch in the loop body */
+                    my_list[flagged ? n_redo + below : (uint32_t)(H2Y_REDO_CAP - 1)] = id_base + tt;
+                    n_redo += (uint32_t)__popcll(m);
                 }
             }
-            tile_store<OUT_KIND>(io, t, W, H, o);
-            /* tiles to redo (a few lanes of about one wave in four at 12 bits; whole waves on black bars):
-             * the wave's 64-bit lane mask, zero or not, goes to the wave's own slot -- no atomics, no
-             * counters.  tt = 64 * slot + lane. */
-            {
-                const uint64_t m = __ballot(tt < a.tiles_per_frame && redo_n != 0);
-                gstore<uint64_t>(a.patch_mask, (uint32_t)f * a.patch_stride + tt / WAVE, m);
+            if (n_redo >= WAVE) { /* 64 tiles to redo: one per lane */
+                n_redo -= WAVE;
+                redo_pass<IN_KIND, OUT_KIND, MODE, PIPE>(&s_rc, &s_pp, s_t2, my_list, n_redo, WAVE);
+                have = false; /* the prefetched tile is not carried through the pass (registers): it is asked for again */
             }
-            IN::load4(src[0], t2.i1, v.g1);
-            IN::load4(src[1], t2.i1, v.b1);
-            IN::load4(src[2], t2.i1, v.r1);
-            t_cur = t2;
         }
         wave_store_mm(mm, a.partial + (((size_t)f * G + blockIdx.x) * (H2Y_T1_THREADS / WAVE) + threadIdx.x / WAVE) * 6);
     }
-}
-
-/*
- * k_patch: the tiles k_fused_t1 flagged, redone by the exact tiers (tables from HBM/L2) and
- * stored over T1's provisional output.  grid = (ceil(slots / 256), n_frames).  A block reads
- * 256 wave masks, expands the set bits into a compact tile list in LDS (block prefix sum) and
- * then works through that list with all its lanes busy.
- */
-#define H2Y_PATCH_THREADS 256
-template <int IN_KIND, int OUT_KIND, int MODE, int PIPE>
-__global__ __launch_bounds__(H2Y_PATCH_THREADS) void k_patch(fused_args a)
-{
-    __shared__ pix_params s_pp;
-    __shared__ uint32_t s_list[H2Y_PATCH_THREADS * WAVE];
-    __shared__ uint32_t s_wave_total[H2Y_PATCH_THREADS / WAVE];
-    const pix_params pp = with_assumed(a.pp, a.assumed);
-    if (threadIdx.x == 0) s_pp = pp;
-    const int f = blockIdx.y;
-    const uint32_t n_slots = (a.tiles_per_frame + WAVE - 1) / WAVE; /* slots past it exist (whole waves past the frame's end) and hold 0 */
-    const uint32_t slot = blockIdx.x * H2Y_PATCH_THREADS + threadIdx.x;
-    const uint64_t m = slot < n_slots ? a.patch_mask[(size_t)f * a.patch_stride + slot] : 0ull;
-    const uint32_t lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
-    /* exclusive prefix sum of the popcounts over the block */
-    const uint32_t c = (uint32_t)__popcll(m);
-    uint32_t incl = c;
-#pragma unroll
-    for (int o = 1; o < WAVE; o <<= 1) {
-        const uint32_t up = __shfl_up(incl, o, WAVE);
-        if (lane >= (uint32_t)o) incl += up;
-    }
-    if (lane == WAVE - 1) s_wave_total[wave] = incl;
-    __syncthreads();
-    uint32_t off = incl - c, total = 0;
-#pragma unroll
-    for (int w = 0; w < H2Y_PATCH_THREADS / WAVE; w++) {
-        const uint32_t t = s_wave_total[w];
-        if ((uint32_t)w < wave) off += t;
-        total += t;
-    }
-    for (uint64_t r = m; r; r &= r - 1) s_list[off++] = slot * WAVE + (uint32_t)__ffsll((unsigned long long)r) - 1u;
-    __syncthreads();
-    if (total == 0) return;
-    const frame_io io = uniform_io(a.frames + f);
-    const pq_recA *gA = static_cast<const pq_recA *>(a.table);
-    const pq_recB *gB = reinterpret_cast<const pq_recB *>(gA + H2Y_PQ_NREC);
-    for (uint32_t i = threadIdx.x; i < total; i += H2Y_PATCH_THREADS) {
-        const tile_pos t = tile_locate(s_list[i], a.width, a.height, a.wq, a.wq_magic);
-        tile_in v;
-        tile_load<IN_KIND>(io, t, v);
-        tile_out o;
-        tile_exact<OUT_KIND, MODE, PIPE>(pp, &s_pp, gA, gB, v, o);
-        tile_store<OUT_KIND>(io, t, a.width, a.height, o);
-    }
+    if (n_redo) redo_pass<IN_KIND, OUT_KIND, MODE, PIPE>(&s_rc, &s_pp, s_t2, my_list, 0u, n_redo);
+    (void)lane;
 }
 
 /*
@@ -1165,28 +1154,6 @@ template <int IN_KIND> static fused_fn pick_t1_out(int out_kind, int mode, int p
     case H2Y_OUT_444: return pick_t1_mode<IN_KIND, H2Y_OUT_444>(mode, pipe);
     default: return pick_t1_mode<IN_KIND, H2Y_OUT_444TMP>(mode, pipe);
     }
-}
-template <int IN_KIND, int OUT_KIND> static fused_fn pick_patch_mode(int mode, int pipe)
-{
-    if (mode == H2Y_MODE_YCBCR)
-        return pipe == 4 ? k_patch<IN_KIND, OUT_KIND, H2Y_MODE_YCBCR, H2Y_PIPE_PQ_IDENT> : k_patch<IN_KIND, OUT_KIND, H2Y_MODE_YCBCR, H2Y_PIPE_PQ_NORM>;
-    return pipe == 4 ? k_patch<IN_KIND, OUT_KIND, H2Y_MODE_YDZDX, H2Y_PIPE_PQ_IDENT> : k_patch<IN_KIND, OUT_KIND, H2Y_MODE_YDZDX, H2Y_PIPE_PQ_NORM>;
-}
-template <int IN_KIND> static fused_fn pick_patch_out(int out_kind, int mode, int pipe)
-{
-    switch (out_kind) {
-    case H2Y_OUT_420BOX: return pick_patch_mode<IN_KIND, H2Y_OUT_420BOX>(mode, pipe);
-    case H2Y_OUT_444: return pick_patch_mode<IN_KIND, H2Y_OUT_444>(mode, pipe);
-    default: return pick_patch_mode<IN_KIND, H2Y_OUT_444TMP>(mode, pipe);
-    }
-}
-bool h2y_fused_needs_patch(const fused_variant &v) { return !v.narrow && (v.pipe == 4 || v.pipe == 5); }
-hipError_t h2y_launch_patch(const fused_variant &v, hipStream_t st, const fused_args &a)
-{
-    fused_fn fn = v.in_kind == H2Y_IN_F16 ? pick_patch_out<H2Y_IN_F16>(v.out_kind, v.mode, v.pipe) : pick_patch_out<H2Y_IN_F32>(v.out_kind, v.mode, v.pipe);
-    const uint32_t n_slots = (a.tiles_per_frame + WAVE - 1) / WAVE;
-    hipLaunchKernelGGL(fn, dim3((n_slots + H2Y_PATCH_THREADS - 1) / H2Y_PATCH_THREADS, a.n_frames), dim3(H2Y_PATCH_THREADS), 0, st, a);
-    return hipGetLastError();
 }
 const char *h2y_fused_name(const fused_variant &v)
 {

@@ -433,3 +433,32 @@ def test_black_bars_and_out_of_table_samples(ctx, oracle, depth, mat, chroma, re
     got = ctx.convert_frame(d2, planes)
     want = oracle.convert_frame(_to_oracle_desc(d2), planes)
     assert np.array_equal(got, want), f"{np.count_nonzero(got != want)} samples differ (measured stats)"
+
+
+@pytest.mark.parametrize("depth,mat,chroma,res", [(12, h.MATRIX_BT2020NC, h.CHROMA_420, 0), (10, h.MATRIX_YDZDX, h.CHROMA_444, 0),
+                                                  (12, h.MATRIX_BT709, h.CHROMA_420, 1)])
+def test_batch_redo_lists_across_frames(ctx, oracle, depth, mat, chroma, res):
+    """One launch over many frames: the first-tier kernel prefetches across frame boundaries and its
+    per-wave redo lists hold tiles of several frames (uniform noise: a few per frame; the frames with
+    black bars: every tile of the bars)."""
+    import torch
+
+    rng = np.random.default_rng(4242 + depth)
+    w, hh = 512, 96
+    d = h.make_desc(w, hh, dst_depth=depth, dst_matrix=mat, chroma=chroma, resampler=res)
+    host = []
+    for k in range(10):
+        planes = _picture_like(rng, w, hh) if k % 3 == 1 else [rng.uniform(0.0, 1.0, w * hh).astype(np.float32) for _ in range(3)]
+        for p in planes:
+            p[(7 * k) % 64] = 1.0  # pic_stats ceiling 1 for every frame
+        host.append(planes)
+    dev_in = [[torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in fr] for fr in host]
+    nb = h.frame_bytes(d)
+    dev_out = [torch.zeros(nb // 2, dtype=torch.int16, device="cuda") for _ in host]
+    torch.cuda.synchronize()
+    ctx.convert_batch(d, dev_in, dev_out)
+    od = _to_oracle_desc(d)
+    for f in range(len(host)):
+        got = dev_out[f].cpu().numpy().view(np.uint16)
+        want = oracle.convert_frame(od, host[f])
+        assert np.array_equal(got, want), f"frame {f}: {np.count_nonzero(got != want)} samples differ"

@@ -267,6 +267,7 @@ fused_variant pick_variant(const h2y_desc *d, const pix_params &pp, int out_kind
     v.out_kind = out_kind;
     v.mode = pp.mode;
     v.narrow = (d->width % 4) != 0;
+    v.even_h = (d->height & 1) == 0;
     v.pipe = 0;
     if (pp.convert_transfer && !v.narrow) {
         bool ident = known != nullptr;
@@ -813,6 +814,7 @@ int h2y_matrix_convert(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3
     var.out_kind = H2Y_OUT_444TMP;
     var.mode = pp.mode;
     var.narrow = (d->width % 4) != 0;
+    var.even_h = (d->height & 1) == 0;
     var.pipe = (pp.convert_transfer == 1 && !var.narrow) ? 2 : 0;
     const geom g = make_geom(d, h2y_fused_threads(var));
     frame_io io;

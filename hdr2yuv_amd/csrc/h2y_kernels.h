@@ -70,6 +70,7 @@ struct fused_variant {
                       3 as 1 for half input through the 16 384-entry table (k_fused_lut16),
                       4 / 5 as 1 / 2 with the binary32 first tier in front (k_fused_t1) */
     bool narrow;   /* width % 4 != 0: scalar-load variant */
+    bool even_h;   /* height % 2 == 0: the branch-free loop forms (k_fused2, k_fused_t1) apply */
 };
 
 struct stats_args {

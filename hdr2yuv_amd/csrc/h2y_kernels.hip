@@ -546,6 +546,108 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
 }
 
 /*
+ * k_fused2: k_fused's work (binary64 tier for every sample) in the loop form of k_fused_t1 below --
+ * row-wise tiles with rolling prefetch, one basic block of memory operations, no divergence around
+ * them (see the comment in k_fused_t1).  LINEAR -> PQ with compile-time MODE and PIPE, even height.
+ * The rare cases stay inside the loop, as branches without memory operations: a sample whose
+ * binary64 value is too close to a rounding tie (1 in 63 763, or outside the table) goes through
+ * pq_slow() alone -- not its whole pixel --, a pixel whose reciprocal-division guard fires gets the
+ * IEEE divisions.
+ */
+template <int PIPE>
+__device__ __forceinline__ float pq_sample(const pix_params &pp, int c, float raw, const pq_recA *sA, const pq_recB *sB, bool &any_slow)
+{
+    const float x = norm1<PIPE>(pp, c, raw);
+    bool slow;
+    float v = pq_fast(x, sA, sB, &slow);
+    if (__builtin_expect(slow, 0)) v = pq_slow(x);
+    any_slow |= slow;
+    return v;
+}
+template <int IN_KIND, int OUT_KIND, int MODE, int PIPE>
+__global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused2(fused_args a)
+{
+    __shared__ pq_recA s_tab[2 * H2Y_PQ_NREC]; /* A records, then B records */
+    const pq_recA *sA = s_tab;
+    const pq_recB *sB = reinterpret_cast<const pq_recB *>(s_tab + H2Y_PQ_NREC);
+    stage_table<H2Y_FUSED_THREADS>(a.table, s_tab);
+    const pix_params pp = with_assumed(a.pp, a.assumed);
+    __syncthreads();
+
+    const uint32_t W = a.width, H = a.height, G = gridDim.x;
+    tile_in v;         /* the tile being worked on; refilled row by row with the next one */
+    tile_pos t_cur;    /* and where it is */
+    bool have = false; /* v holds the tile this block meets next (uniform) */
+    typedef in_traits<IN_KIND> IN;
+    for (int f = 0; f < a.n_frames; f++) {
+        const frame_io io = uniform_io(a.frames + f);
+        const frame_io io_next = uniform_io(a.frames + (f + 1 < a.n_frames ? f + 1 : f));
+        mm6 mm;
+        mm.reset();
+        const uint32_t gbase = (uint32_t)(((uint64_t)f * a.chunks_per_frame) % G);
+        const uint32_t k_next_frame = (uint32_t)((blockIdx.x + G - (uint32_t)(((uint64_t)(f + 1) * a.chunks_per_frame) % G)) % G);
+        uint32_t k = (blockIdx.x + G - gbase) % G;
+        if (!have && k < a.chunks_per_frame) {
+            t_cur = tile_locate(umin32(k * H2Y_FUSED_THREADS + threadIdx.x, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
+            tile_load<IN_KIND>(io, t_cur, v);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                asm volatile("" ::"v"(v.g0[j]), "v"(v.b0[j]), "v"(v.r0[j]), "v"(v.g1[j]), "v"(v.b1[j]), "v"(v.r1[j]));
+        }
+        for (; k < a.chunks_per_frame; k += G) {
+            tile_pos t = t_cur;
+            t.row1 = true;
+            uint32_t k2 = k + G;
+            const bool same = k2 < a.chunks_per_frame;
+            if (!same) k2 = k_next_frame;
+            have = same || (f + 1 < a.n_frames && k2 < a.chunks_per_frame);
+            if (!have) k2 = k;
+            const tile_pos t2 = tile_locate(umin32(k2 * H2Y_FUSED_THREADS + threadIdx.x, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
+            const void *src[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) src[c] = (!same && have) ? io_next.in[c] : io.in[c];
+
+            tile_out o;
+            uint32_t sb[2], sr[2];
+#pragma unroll
+            for (int row = 0; row < 2; row++) {
+                const float(&gv)[4] = row ? v.g1 : v.g0;
+                const float(&bv)[4] = row ? v.b1 : v.b0;
+                const float(&rv)[4] = row ? v.r1 : v.r0;
+                mm.add2(0, gv[0], gv[1]); mm.add2(0, gv[2], gv[3]);
+                mm.add2(1, bv[0], bv[1]); mm.add2(1, bv[2], bv[3]);
+                mm.add2(2, rv[0], rv[1]); mm.add2(2, rv[2], rv[3]);
+                uint32_t Y[4], Cb[4], Cr[4];
+#pragma unroll
+                for (int col = 0; col < 4; col++) {
+                    bool odd = false; /* a sample went through pq_slow(): it may be NaN (negative input, 0/0 normalisation) */
+                    const float g = pix_scale(pq_sample<PIPE>(pp, 0, gv[col], sA, sB, odd), pp.mulY, pp.addY);
+                    const float b = pix_scale(pq_sample<PIPE>(pp, 1, bv[col], sA, sB, odd), pp.mulC, pp.addC);
+                    const float r = pix_scale(pq_sample<PIPE>(pp, 2, rv[col], sA, sB, odd), pp.mulC, pp.addC);
+                    bool um;
+                    pix_matrix<MODE, false>(pp, g, b, r, Y[col], Cb[col], Cr[col], &um);
+                    /* the careful form of the matrix: IEEE divisions, the reference's NaN conversions */
+                    if (__builtin_expect(um | odd, 0)) pix_matrix<MODE, true>(pp, g, b, r, Y[col], Cb[col], Cr[col], &um);
+                }
+                row_pack<OUT_KIND>(pp, row, Y, Cb, Cr, o, sb, sr);
+                if (row == 0) {
+                    IN::load4(src[0], t2.i0, v.g0);
+                    IN::load4(src[1], t2.i0, v.b0);
+                    IN::load4(src[2], t2.i0, v.r0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            tile_store<OUT_KIND>(io, t, W, H, o);
+            IN::load4(src[0], t2.i1, v.g1);
+            IN::load4(src[1], t2.i1, v.b1);
+            IN::load4(src[2], t2.i1, v.r1);
+            t_cur = t2;
+        }
+        wave_store_mm(mm, a.partial + (((size_t)f * G + blockIdx.x) * (H2Y_FUSED_THREADS / WAVE) + threadIdx.x / WAVE) * 6);
+    }
+}
+
+/*
  * k_fused_t1: the same work with a binary32 FIRST TIER in front (LINEAR -> PQ, YCbCr or YDzDx,
  * float input, even height).
  *
@@ -1112,19 +1214,19 @@ __global__ __launch_bounds__(256) void k_fir420(fir_args a)
 /* ---- launch helpers (called from h2y_api.hip) --------------------------- */
 typedef void (*fused_fn)(fused_args);
 
-template <int IN_KIND, int OUT_KIND, int MODE> static fused_fn pick_pipe(int pipe)
+template <int IN_KIND, int OUT_KIND, int MODE> static fused_fn pick_pipe(int pipe, bool even_h)
 {
     switch (pipe) {
-    case H2Y_PIPE_PQ_IDENT: return k_fused<IN_KIND, OUT_KIND, MODE, H2Y_PIPE_PQ_IDENT>;
-    case H2Y_PIPE_PQ_NORM: return k_fused<IN_KIND, OUT_KIND, MODE, H2Y_PIPE_PQ_NORM>;
+    case H2Y_PIPE_PQ_IDENT: return even_h ? k_fused2<IN_KIND, OUT_KIND, MODE, H2Y_PIPE_PQ_IDENT> : k_fused<IN_KIND, OUT_KIND, MODE, H2Y_PIPE_PQ_IDENT>;
+    case H2Y_PIPE_PQ_NORM: return even_h ? k_fused2<IN_KIND, OUT_KIND, MODE, H2Y_PIPE_PQ_NORM> : k_fused<IN_KIND, OUT_KIND, MODE, H2Y_PIPE_PQ_NORM>;
     default: return k_fused<IN_KIND, OUT_KIND, MODE, H2Y_PIPE_RUNTIME>;
     }
 }
-template <int IN_KIND, int OUT_KIND> static fused_fn pick_mode(int mode, int pipe)
+template <int IN_KIND, int OUT_KIND> static fused_fn pick_mode(int mode, int pipe, bool even_h)
 {
     switch (mode) {
-    case H2Y_MODE_YCBCR: return pick_pipe<IN_KIND, OUT_KIND, H2Y_MODE_YCBCR>(pipe);
-    case H2Y_MODE_YDZDX: return pick_pipe<IN_KIND, OUT_KIND, H2Y_MODE_YDZDX>(pipe);
+    case H2Y_MODE_YCBCR: return pick_pipe<IN_KIND, OUT_KIND, H2Y_MODE_YCBCR>(pipe, even_h);
+    case H2Y_MODE_YDZDX: return pick_pipe<IN_KIND, OUT_KIND, H2Y_MODE_YDZDX>(pipe, even_h);
     default: return k_fused<IN_KIND, OUT_KIND, H2Y_MODE_RUNTIME, H2Y_PIPE_RUNTIME>; /* identity / Y100 / Y500: generic */
     }
 }
@@ -1132,9 +1234,9 @@ template <int IN_KIND> static fused_fn pick_out(const fused_variant &v)
 {
     if (v.narrow) return v.out_kind == H2Y_OUT_444 ? k_fused_narrow<IN_KIND, H2Y_OUT_444> : k_fused_narrow<IN_KIND, H2Y_OUT_444TMP>;
     switch (v.out_kind) {
-    case H2Y_OUT_420BOX: return pick_mode<IN_KIND, H2Y_OUT_420BOX>(v.mode, v.pipe);
-    case H2Y_OUT_444: return pick_mode<IN_KIND, H2Y_OUT_444>(v.mode, v.pipe);
-    default: return pick_mode<IN_KIND, H2Y_OUT_444TMP>(v.mode, v.pipe);
+    case H2Y_OUT_420BOX: return pick_mode<IN_KIND, H2Y_OUT_420BOX>(v.mode, v.pipe, v.even_h);
+    case H2Y_OUT_444: return pick_mode<IN_KIND, H2Y_OUT_444>(v.mode, v.pipe, v.even_h);
+    default: return pick_mode<IN_KIND, H2Y_OUT_444TMP>(v.mode, v.pipe, v.even_h);
     }
 }
 template <int OUT_KIND> static fused_fn pick_lut_mode(int mode)
@@ -1159,7 +1261,8 @@ const char *h2y_fused_name(const fused_variant &v)
 {
     if (v.narrow) return "k_fused_narrow";
     if (v.pipe == 3) return "k_fused_lut16";
-    return (v.pipe == 4 || v.pipe == 5) ? "k_fused_t1" : "k_fused";
+    if (v.pipe == 4 || v.pipe == 5) return "k_fused_t1";
+    return ((v.pipe == 1 || v.pipe == 2) && v.even_h && (v.mode == H2Y_MODE_YCBCR || v.mode == H2Y_MODE_YDZDX)) ? "k_fused2" : "k_fused";
 }
 int h2y_fused_threads(const fused_variant &v) { return (v.pipe == 4 || v.pipe == 5) ? H2Y_T1_THREADS : H2Y_FUSED_THREADS; }
 

@@ -277,7 +277,7 @@ fused_variant pick_variant(const h2y_desc *d, const pix_params &pp, int out_kind
         /* binary32 first tier where few pixels would fall through it (moderate bit depths) */
         if ((v.pipe == 1 || v.pipe == 2) && v.in_kind != H2Y_IN_U16 && (d->height & 1) == 0 && t1_enabled() && t1_bounds(pp, sn)) v.pipe += 3;
         /* half input with the identity normalisation: the whole transfer is a 64 KB table */
-        if (ident && v.in_kind == H2Y_IN_F16 && (pp.mode == H2Y_MODE_YCBCR || pp.mode == H2Y_MODE_YDZDX)) v.pipe = 3;
+        if (ident && v.in_kind == H2Y_IN_F16 && v.even_h && (pp.mode == H2Y_MODE_YCBCR || pp.mode == H2Y_MODE_YDZDX)) v.pipe = 3;
     }
     return v;
 }

@@ -876,8 +876,14 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
     __syncthreads();
 
     const uint32_t W = a.width, H = a.height, G = gridDim.x;
+    /* the loop form of k_fused_t1: row-wise tiles, rolling prefetch (8-byte loads: four halves), one
+     * basic block of memory operations; even height (the host sends odd heights to k_fused) */
+    u32x2 raw[3][2];   /* the tile being worked on, raw halves: [plane][row], four samples each */
+    tile_pos t_cur;
+    bool have = false;
     for (int f = 0; f < a.n_frames; f++) {
         const frame_io io = uniform_io(a.frames + f);
+        const frame_io io_next = uniform_io(a.frames + (f + 1 < a.n_frames ? f + 1 : f));
         /* packed-half accumulators: {min, max} x plane, two halves per dword */
         uint32_t mn[3], mx[3];
 #pragma unroll
@@ -886,45 +892,69 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
             mx[c] = 0x00000000u; /* +0: FLT_MIN (1.2e-38) is below the smallest half; (int) of either is 0 */
         }
         const uint32_t gbase = (uint32_t)(((uint64_t)f * a.chunks_per_frame) % G);
+        const uint32_t k_next_frame = (uint32_t)((blockIdx.x + G - (uint32_t)(((uint64_t)(f + 1) * a.chunks_per_frame) % G)) % G);
         uint32_t k = (blockIdx.x + G - gbase) % G;
-        for (; k < a.chunks_per_frame; k += G) {
-            const uint32_t tt = k * H2Y_FUSED_THREADS + threadIdx.x;
-            if (tt >= a.tiles_per_frame) continue;
-            const tile_pos t = tile_locate(tt, W, H, a.wq, a.wq_magic);
-            /* raw halves: [plane][row] as two dwords (4 samples) */
-            uint2 raw[3][2];
+        if (!have && k < a.chunks_per_frame) {
+            t_cur = tile_locate(umin32(k * H2Y_FUSED_THREADS + threadIdx.x, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                { const u32x2 q0 = gload<u32x2>(io.in[c], t.i0 >> 2); raw[c][0] = make_uint2(q0.x, q0.y); }
-                { const u32x2 q1 = gload<u32x2>(io.in[c], t.i1 >> 2); raw[c][1] = make_uint2(q1.x, q1.y); }
-                mn[c] = pk_min_h(pk_min_h(mn[c], raw[c][0].x), pk_min_h(raw[c][0].y, pk_min_h(raw[c][1].x, raw[c][1].y)));
-                mx[c] = pk_max_h(pk_max_h(mx[c], raw[c][0].x), pk_max_h(raw[c][0].y, pk_max_h(raw[c][1].x, raw[c][1].y)));
+                raw[c][0] = gload<u32x2>(io.in[c], t_cur.i0 >> 2);
+                raw[c][1] = gload<u32x2>(io.in[c], t_cur.i1 >> 2);
             }
-            tile_out o;
 #pragma unroll
-            for (int jb = 0; jb < 2; jb++) {
+            for (int c = 0; c < 3; c++)
+                asm volatile("" ::"v"(raw[c][0].x), "v"(raw[c][0].y), "v"(raw[c][1].x), "v"(raw[c][1].y));
+        }
+        for (; k < a.chunks_per_frame; k += G) {
+            tile_pos t = t_cur;
+            t.row1 = true;
+            uint32_t k2 = k + G;
+            const bool same = k2 < a.chunks_per_frame;
+            if (!same) k2 = k_next_frame;
+            have = same || (f + 1 < a.n_frames && k2 < a.chunks_per_frame);
+            if (!have) k2 = k;
+            const tile_pos t2 = tile_locate(umin32(k2 * H2Y_FUSED_THREADS + threadIdx.x, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
+            const void *src[3];
+#pragma unroll
+            for (int c = 0; c < 3; c++) src[c] = (!same && have) ? io_next.in[c] : io.in[c];
+            tile_out o;
+            uint32_t sb[2], sr[2];
+#pragma unroll
+            for (int row = 0; row < 2; row++) {
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    mn[c] = pk_min_h(pk_min_h(mn[c], raw[c][row].x), raw[c][row].y);
+                    mx[c] = pk_max_h(pk_max_h(mx[c], raw[c][row].x), raw[c][row].y);
+                }
                 uint32_t Y[4], Cb[4], Cr[4];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const int row = q >> 1, hi = q & 1; /* column 2*jb + hi of the tile */
-                    const uint32_t wg = jb ? raw[0][row].y : raw[0][row].x;
-                    const uint32_t wb = jb ? raw[1][row].y : raw[1][row].x;
-                    const uint32_t wr = jb ? raw[2][row].y : raw[2][row].x;
-                    const uint32_t hg = hi ? wg >> 16 : wg & 0xFFFFu, hb = hi ? wb >> 16 : wb & 0xFFFFu, hr = hi ? wr >> 16 : wr & 0xFFFFu;
+                for (int col = 0; col < 4; col++) {
+                    const uint32_t wg = col & 2 ? raw[0][row].y : raw[0][row].x;
+                    const uint32_t wb = col & 2 ? raw[1][row].y : raw[1][row].x;
+                    const uint32_t wr = col & 2 ? raw[2][row].y : raw[2][row].x;
+                    const uint32_t hg = col & 1 ? wg >> 16 : wg & 0xFFFFu, hb = col & 1 ? wb >> 16 : wb & 0xFFFFu, hr = col & 1 ? wr >> 16 : wr & 0xFFFFu;
                     const float g = pix_scale(s_lut[hg & (H2Y_LUT16_N - 1)], pp.mulY, pp.addY);
                     const float b = pix_scale(s_lut[hb & (H2Y_LUT16_N - 1)], pp.mulC, pp.addC);
                     const float r = pix_scale(s_lut[hr & (H2Y_LUT16_N - 1)], pp.mulC, pp.addC);
                     bool um;
-                    pix_matrix<MODE, false>(pp, g, b, r, Y[q], Cb[q], Cr[q], &um);
+                    pix_matrix<MODE, false>(pp, g, b, r, Y[col], Cb[col], Cr[col], &um);
                     const bool outside = ((hg | hb | hr) & ~(uint32_t)(H2Y_LUT16_N - 1)) != 0; /* negative, >= 2.0, inf, NaN */
                     if (__builtin_expect(outside | um, 0)) {
                         const ycc c = pixel_careful<MODE>(&s_pp, half_bits_to_float(hg), half_bits_to_float(hb), half_bits_to_float(hr));
-                        Y[q] = c.y; Cb[q] = c.cb; Cr[q] = c.cr;
+                        Y[col] = c.y; Cb[col] = c.cb; Cr[col] = c.cr;
                     }
                 }
-                tile_pack<OUT_KIND>(pp, jb, Y, Cb, Cr, o);
+                row_pack<OUT_KIND>(pp, row, Y, Cb, Cr, o, sb, sr);
+                if (row == 0) {
+#pragma unroll
+                    for (int c = 0; c < 3; c++) raw[c][0] = gload<u32x2>(src[c], t2.i0 >> 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             tile_store<OUT_KIND>(io, t, W, H, o);
+#pragma unroll
+            for (int c = 0; c < 3; c++) raw[c][1] = gload<u32x2>(src[c], t2.i1 >> 2);
+            t_cur = t2;
         }
         mm6 mm;
 #pragma unroll

@@ -707,7 +707,10 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
         stage_table<H2Y_T1_THREADS>(a.table, s_t2);
     }
     const pix_params pp = with_assumed(a.pp, a.assumed);
-    const t1_sens sn = a.sn;
+    t1_sens sn = a.sn;
+    /* the two window constants selected per pixel (v_cndmask_b32 wants one operand in a vector register):
+     * kept in registers for the whole kernel instead of being moved there for every pixel */
+    asm volatile("" : "+v"(sn.c_lo), "+v"(sn.c_span));
     if (threadIdx.x == 0) {
         s_pp = pp;
         s_rc.frames = a.frames;

@@ -507,7 +507,13 @@ struct alignas(16) pq_rec1 {
 /* the real-number value of the T1 evaluation, as (c0h, 2^25 w); shared with tools */
 H2Y_FN void pq_t1_parts(uint32_t bits, const pq_rec1 &r, float *c0h, float *w)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t fb; /* one v_and_or_b32 (the compiler splits it into and + or) */
+    asm("v_and_or_b32 %0, %1, %2, 1.0" : "=v"(fb) : "v"(bits), "s"((1u << H2Y_T1_LOW_BITS) - 1u));
+    float f = bits2f(fb);
+#else
     float f = bits2f((bits & ((1u << H2Y_T1_LOW_BITS) - 1u)) | 0x3F800000u);
+#endif
     float u = f - (1.0f + 1.0f / (float)(2 << H2Y_T1_SEG_BITS));
     *w = __builtin_fmaf(__builtin_fmaf(r.c2, u, r.c1), u, r.c0l);
     *c0h = r.c0h;
@@ -550,7 +556,13 @@ H2Y_FN float pq_t1(float x, const pq_rec1 *__restrict__ T, bool *unsure)
     /* |e| against ulp(s)/2 - delta with delta = RELERR*s <= RELERR * 2^25 * ulp(s)/2: one constant factor
      * (1 - RELERR*2^25) of ulp(s)/2; times 2^25 that is s's exponent with that factor's mantissa
      * (1.98...), which v_and_or_b32 builds in one instruction -- hence the scaled w */
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t tb; /* written out for the same reason as in pq_t1_parts(); one operand may be scalar, the other sits in a register */
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(tb) : "v"(f2bits(s)), "s"(0x7F800000u), "v"(H2Y_T1_THR_MANT));
+    const float thr = bits2f(tb);
+#else
     const float thr = bits2f((f2bits(s) & 0x7F800000u) | H2Y_T1_THR_MANT);
+#endif
     *unsure = !(__builtin_fabsf(es) < thr); /* NaN (sentinel record) => unsure */
     return s;
 }

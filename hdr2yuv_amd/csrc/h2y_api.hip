@@ -53,7 +53,7 @@ clip_limits make_clip(int bit_depth, int full_range)
 }
 
 const int kMaxEvents = 64;
-const int kFirSubBatch = 8;
+const int kFirSubBatch = 32; /* frames per fused launch on the FIR path: every launch pays its table staging and its last redo pass */
 
 } // namespace
 
@@ -269,6 +269,8 @@ fused_variant pick_variant(const h2y_desc *d, const pix_params &pp, int out_kind
     v.narrow = (d->width % 4) != 0;
     v.even_h = (d->height & 1) == 0;
     v.pipe = 0;
+    /* equal transfers (the 16-bit .tiff / .yuv flows): samples straight into the matrix */
+    if (!pp.convert_transfer && !v.narrow && v.even_h && (pp.mode == H2Y_MODE_YCBCR || pp.mode == H2Y_MODE_YDZDX)) v.pipe = 6;
     if (pp.convert_transfer && !v.narrow) {
         bool ident = known != nullptr;
         for (int c = 0; c < 3 && ident; c++) ident = known->floor_[c] == 0 && known->ceil_[c] == 1;

@@ -68,7 +68,8 @@ struct fused_variant {
     int in_kind, out_kind, mode;
     int pipe;      /* 0 runtime flags, 1 LINEAR->PQ with floor 0/ceiling 1, 2 LINEAR->PQ general normalisation,
                       3 as 1 for half input through the 16 384-entry table (k_fused_lut16),
-                      4 / 5 as 1 / 2 with the binary32 first tier in front (k_fused_t1) */
+                      4 / 5 as 1 / 2 with the binary32 first tier in front (k_fused_t1),
+                      6 equal transfers, no PQ at all (k_fused2) */
     bool narrow;   /* width % 4 != 0: scalar-load variant */
     bool even_h;   /* height % 2 == 0: the branch-free loop forms (k_fused2, k_fused_t1) apply */
 };

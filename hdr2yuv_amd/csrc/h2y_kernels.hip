@@ -233,6 +233,7 @@ __device__ __attribute__((noinline)) ycc pixel_careful(const pix_params *spp /* 
 #define H2Y_PIPE_RUNTIME 0  /* read pp.convert_transfer / pp.norm_identity */
 #define H2Y_PIPE_PQ_IDENT 1 /* LINEAR -> PQ, floor 0 / ceiling 1: no normalisation arithmetic */
 #define H2Y_PIPE_PQ_NORM 2  /* LINEAR -> PQ with (x - offset) / range */
+#define H2Y_PIPE_NONE 6     /* equal transfers: the samples go to the matrix as they are (k_fused2 only) */
 
 /* normalisation of one sample, convert.cpp:1017-1019: binary32 subtract, IEEE divide */
 template <int PIPE> __device__ __forceinline__ float norm1(const pix_params &pp, int c, float v)
@@ -557,20 +558,21 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
 template <int PIPE>
 __device__ __forceinline__ float pq_sample(const pix_params &pp, int c, float raw, const pq_recA *sA, const pq_recB *sB, bool &any_slow)
 {
+    if (PIPE == H2Y_PIPE_NONE) return raw; /* convert.cpp:930: no transfer conversion, no normalisation, no scale step */
     const float x = norm1<PIPE>(pp, c, raw);
     bool slow;
     float v = pq_fast(x, sA, sB, &slow);
     if (__builtin_expect(slow, 0)) v = pq_slow(x);
     any_slow |= slow;
-    return v;
+    return pix_scale(v, c == 0 ? pp.mulY : pp.mulC, c == 0 ? pp.addY : pp.addC);
 }
 template <int IN_KIND, int OUT_KIND, int MODE, int PIPE>
 __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused2(fused_args a)
 {
-    __shared__ pq_recA s_tab[2 * H2Y_PQ_NREC]; /* A records, then B records */
+    __shared__ pq_recA s_tab[PIPE == H2Y_PIPE_NONE ? 1 : 2 * H2Y_PQ_NREC]; /* A records, then B records */
     const pq_recA *sA = s_tab;
-    const pq_recB *sB = reinterpret_cast<const pq_recB *>(s_tab + H2Y_PQ_NREC);
-    stage_table<H2Y_FUSED_THREADS>(a.table, s_tab);
+    const pq_recB *sB = reinterpret_cast<const pq_recB *>(s_tab + (PIPE == H2Y_PIPE_NONE ? 0 : H2Y_PQ_NREC));
+    if (PIPE != H2Y_PIPE_NONE) stage_table<H2Y_FUSED_THREADS>(a.table, s_tab);
     const pix_params pp = with_assumed(a.pp, a.assumed);
     __syncthreads();
 
@@ -621,9 +623,9 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
 #pragma unroll
                 for (int col = 0; col < 4; col++) {
                     bool odd = false; /* a sample went through pq_slow(): it may be NaN (negative input, 0/0 normalisation) */
-                    const float g = pix_scale(pq_sample<PIPE>(pp, 0, gv[col], sA, sB, odd), pp.mulY, pp.addY);
-                    const float b = pix_scale(pq_sample<PIPE>(pp, 1, bv[col], sA, sB, odd), pp.mulC, pp.addC);
-                    const float r = pix_scale(pq_sample<PIPE>(pp, 2, rv[col], sA, sB, odd), pp.mulC, pp.addC);
+                    const float g = pq_sample<PIPE>(pp, 0, gv[col], sA, sB, odd);
+                    const float b = pq_sample<PIPE>(pp, 1, bv[col], sA, sB, odd);
+                    const float r = pq_sample<PIPE>(pp, 2, rv[col], sA, sB, odd);
                     bool um;
                     pix_matrix<MODE, false>(pp, g, b, r, Y[col], Cb[col], Cr[col], &um);
                     /* the careful form of the matrix: IEEE divisions, the reference's NaN conversions */
@@ -1252,6 +1254,7 @@ template <int IN_KIND, int OUT_KIND, int MODE> static fused_fn pick_pipe(int pip
     switch (pipe) {
     case H2Y_PIPE_PQ_IDENT: return even_h ? k_fused2<IN_KIND, OUT_KIND, MODE, H2Y_PIPE_PQ_IDENT> : k_fused<IN_KIND, OUT_KIND, MODE, H2Y_PIPE_PQ_IDENT>;
     case H2Y_PIPE_PQ_NORM: return even_h ? k_fused2<IN_KIND, OUT_KIND, MODE, H2Y_PIPE_PQ_NORM> : k_fused<IN_KIND, OUT_KIND, MODE, H2Y_PIPE_PQ_NORM>;
+    case H2Y_PIPE_NONE: return k_fused2<IN_KIND, OUT_KIND, MODE, H2Y_PIPE_NONE>;
     default: return k_fused<IN_KIND, OUT_KIND, MODE, H2Y_PIPE_RUNTIME>;
     }
 }
@@ -1295,7 +1298,7 @@ const char *h2y_fused_name(const fused_variant &v)
     if (v.narrow) return "k_fused_narrow";
     if (v.pipe == 3) return "k_fused_lut16";
     if (v.pipe == 4 || v.pipe == 5) return "k_fused_t1";
-    return ((v.pipe == 1 || v.pipe == 2) && v.even_h && (v.mode == H2Y_MODE_YCBCR || v.mode == H2Y_MODE_YDZDX)) ? "k_fused2" : "k_fused";
+    return ((v.pipe == 1 || v.pipe == 2 || v.pipe == H2Y_PIPE_NONE) && v.even_h && (v.mode == H2Y_MODE_YCBCR || v.mode == H2Y_MODE_YDZDX)) ? "k_fused2" : "k_fused";
 }
 int h2y_fused_threads(const fused_variant &v) { return (v.pipe == 4 || v.pipe == 5) ? H2Y_T1_THREADS : H2Y_FUSED_THREADS; }
 

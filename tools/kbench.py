@@ -66,6 +66,12 @@ def main():
                 p[0] = 0.0
                 p[1] = 1.0
         timeit(ctx, h.make_desc(w, hh, dst_depth=12, dst_matrix=9, resampler=0), sm, "C2 box smooth ramp input")
+    if on("u16"):
+        # 16-bit integer input, equal transfers (the .tiff/.yuv flows): no PQ, matrix + subsample only
+        rng = np.random.default_rng(3)
+        u = [[torch.from_numpy(rng.integers(0, 65536, w * hh, dtype=np.uint16).view(np.int16)).cuda() for _ in range(3)] for _ in range(F)]
+        timeit(ctx, h.make_desc(w, hh, sample=h.SAMPLE_U16, src_depth=16, dst_depth=10, dst_matrix=9, resampler=0, src_transfer=16, dst_transfer=16), u,
+               "4K u16 RGB -> 10-bit 2020nc 4:2:0 box, equal transfers", bytes_per_px=9.0)
     if on("c1"):
         w1, h1 = 1920, 1080
         s1 = [[torch.from_numpy(p).cuda() for p in synth_frame(w1, h1, k)] for k in range(F)]

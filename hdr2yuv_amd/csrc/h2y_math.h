@@ -911,6 +911,17 @@ H2Y_FN uint32_t pix_box_clamp(const pix_params &pp, uint32_t sum4)
     return umed3(sum4, pp.clo_b, pp.chi_b) >> (pp.down_shift + 2);
 }
 
+/* clamp to [0, maxCV] and truncate (convert.cpp:314-317, 372-374); t is never NaN (sums of finite samples) */
+H2Y_FN uint32_t fir_clamp_trunc(float t, float fmaxcv)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_fmed3f(t, 0.0f, fmaxcv);
+#else
+    if (t > fmaxcv) t = fmaxcv;
+    if (t < 0.0f) t = 0.0f;
+    return (uint32_t)t;
+#endif
+}
 /* Subsample444to420_FIR stage 1, convert.cpp:305-317.  s[-5..5] around an
  * even column, already edge-replicated.  float sums left to right, +0.5
  * (the reference's double add of 0.5 rounded back to float is the same
@@ -921,10 +932,7 @@ H2Y_FN uint32_t fir_h(float m5, float m3, float m1, float c, float p1, float p3,
     float acc = c21 * (m5 + p5) - c52 * (m3 + p3);
     acc = acc + c159 * (m1 + p1);
     acc = acc + c256 * c;
-    float t = acc + 0.5f;
-    if (t > fmaxcv) t = fmaxcv;
-    if (t < 0.0f) t = 0.0f;
-    return (uint32_t)t;
+    return fir_clamp_trunc(acc + 0.5f, fmaxcv);
 }
 
 /* stage 2, convert.cpp:365-374: rows j-5..j+6 of the 4:2:2 intermediate */
@@ -938,10 +946,7 @@ H2Y_FN uint32_t fir_v(float m5, float m4, float m3, float m2, float m1, float m0
     acc = acc - c21 * (m3 + p4);
     acc = acc + c11 * (m4 + p5);
     acc = acc + c5 * (m5 + p6);
-    float t = acc + 0.5f;
-    if (t > fmaxcv) t = fmaxcv;
-    if (t < 0.0f) t = 0.0f;
-    return (uint32_t)t;
+    return fir_clamp_trunc(acc + 0.5f, fmaxcv);
 }
 
 } // namespace h2y

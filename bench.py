@@ -222,6 +222,23 @@ def main():
             traffic = tj.get(f"{args.workload}_{args.resampler}_F{F}", {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+    # a plain device-to-device copy of 1 GiB on this very box, as the practical HBM ceiling beside the 8 TB/s spec
+    copy_gbs = None
+    try:
+        src_t = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        dst_t = torch.empty_like(src_t)
+        for _ in range(2):
+            dst_t.copy_(src_t)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            dst_t.copy_(src_t)
+        e1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 5 * 2 * src_t.numel() * 4 / (e0.elapsed_time(e1) / 1e3) / 1e9
+        del src_t, dst_t
+    except Exception:
+        copy_gbs = None
     out["roofline"] = {
         "bound": "hbm",
         "kernel": main_r["kernel"],
@@ -233,6 +250,8 @@ def main():
         "algorithmic_bytes_per_launch": alg_bytes / launches,
         "launches_per_step": launches,
         "kernel_ms_per_step": round(main_r["kernel_ms"], 4),
+        "device_copy_gbs": None if copy_gbs is None else round(copy_gbs, 1),
+        "frac_of_device_copy": None if not copy_gbs else round(ach / copy_gbs, 4),
     }
     for res, r in results.items():
         if res != args.resampler:

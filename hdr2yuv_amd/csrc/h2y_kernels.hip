@@ -820,11 +820,15 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
                 /* tiles to redo (a few lanes of about one wave in four at 12 bits; whole waves on black
                  * bars) go to the wave's list: position = entries so far + flagged lanes below this one */
                 {
-                    const bool flagged = tt < a.tiles_per_frame && redo_n != 0;
+                    /* Lanes past the frame's end have redone its last tile and stored its provisional bytes
+                     * again -- possibly after the tile's owner already replaced them with the exact ones.  So
+                     * they list the tile too: the last store to a flagged tile is then always a redo_pass()
+                     * store (a wave's own redo follows its own provisional store). */
+                    const bool flagged = redo_n != 0;
                     const uint64_t m = __ballot(flagged);
                     const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                     /* unflagged lanes write to the spare last slot: no branch in the loop body */
-                    my_list[flagged ? n_redo + below : (uint32_t)(H2Y_REDO_CAP - 1)] = id_base + tt;
+                    my_list[flagged ? n_redo + below : (uint32_t)(H2Y_REDO_CAP - 1)] = id_base + umin32(tt, a.tiles_per_frame - 1u);
                     n_redo += (uint32_t)__popcll(m);
                 }
             }

@@ -28,6 +28,7 @@ EXPORTS = [
     "h2y_abi_version", "h2y_frame_bytes", "h2y_plane_bytes", "h2y_desc_check", "h2y_ctx_create", "h2y_ctx_destroy",
     "h2y_last_error", "h2y_ctx_set_stream", "h2y_convert_frame", "h2y_convert_batch", "h2y_convert_batch_enqueue",
     "h2y_batch_finish", "h2y_pic_stats", "h2y_matrix_convert", "h2y_subsample_420", "h2y_last_kernel_ms", "h2y_last_kernel_name",
+    "h2y_stream_open", "h2y_stream_input", "h2y_stream_submit", "h2y_stream_output", "h2y_stream_close",
 ]
 
 
@@ -134,6 +135,16 @@ def load_library():
     L.h2y_matrix_convert.argtypes = [C.c_void_p, C.POINTER(H2YDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.h2y_subsample_420.restype = C.c_int
     L.h2y_subsample_420.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.h2y_stream_open.restype = C.c_int
+    L.h2y_stream_open.argtypes = [C.c_void_p, C.POINTER(H2YDesc), C.c_int]
+    L.h2y_stream_input.restype = C.c_int
+    L.h2y_stream_input.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    L.h2y_stream_submit.restype = C.c_int
+    L.h2y_stream_submit.argtypes = [C.c_void_p]
+    L.h2y_stream_output.restype = C.c_int
+    L.h2y_stream_output.argtypes = [C.c_void_p, C.POINTER(C.POINTER(C.c_uint16))]
+    L.h2y_stream_close.restype = C.c_int
+    L.h2y_stream_close.argtypes = [C.c_void_p]
     L.h2y_last_kernel_name.restype = C.c_char_p
     L.h2y_last_kernel_name.argtypes = [C.c_void_p]
     L.h2y_last_kernel_ms.restype = C.c_int
@@ -253,6 +264,36 @@ class Context:
         n = C.c_int()
         self.lib.h2y_last_kernel_ms(self.h, C.byref(ms), C.byref(n))
         return ms.value, n.value
+
+    # ---- host <-> device pipeline -----------------------------------------------------------
+    def stream_open(self, d, depth=3) -> None:
+        self._check(self.lib.h2y_stream_open(self.h, C.byref(d), depth))
+        self._stream_desc = d
+
+    def stream_input(self):
+        """The three pinned input planes of the next slot, as numpy views to fill in place."""
+        import numpy as np
+
+        ptrs = (C.c_void_p * 3)()
+        self._check(self.lib.h2y_stream_input(self.h, ptrs))
+        d = self._stream_desc
+        n = d.width * d.height
+        dt = np.float32 if d.in_sample_type == SAMPLE_F32 else np.uint16
+        return [np.ctypeslib.as_array(C.cast(ptrs[c], C.POINTER(C.c_float if dt is np.float32 else C.c_uint16)), shape=(n,)) for c in range(3)]
+
+    def stream_submit(self) -> None:
+        self._check(self.lib.h2y_stream_submit(self.h))
+
+    def stream_output(self):
+        """The oldest frame in flight (a numpy view of pinned memory, valid until the next stream_output)."""
+        import numpy as np
+
+        p = C.POINTER(C.c_uint16)()
+        self._check(self.lib.h2y_stream_output(self.h, C.byref(p)))
+        return np.ctypeslib.as_array(p, shape=(frame_bytes(self._stream_desc) // 2,))
+
+    def stream_close(self) -> None:
+        self._check(self.lib.h2y_stream_close(self.h))
 
     def last_kernel_name(self) -> str:
         return (self.lib.h2y_last_kernel_name(self.h) or b"").decode()

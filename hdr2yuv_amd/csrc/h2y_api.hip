@@ -88,6 +88,22 @@ struct h2y_ctx {
     bool have_hint = false;
     int hint_kind = -1;
     int32_t hint_floor[3] = {0, 0, 0}, hint_ceil[3] = {0, 0, 0};
+    /* streaming pipeline (h2y_stream_*): a ring of pinned host slots with device twins */
+    struct stream_slot {
+        char *h_in = nullptr;      /* pinned: three planes, each plane_al bytes apart */
+        uint16_t *h_out = nullptr; /* pinned: one .yuv frame */
+        char *d_in = nullptr;
+        uint16_t *d_out = nullptr;
+        hipEvent_t ev_h2d = nullptr, ev_conv = nullptr, ev_done = nullptr;
+        int state = 0; /* 0 free, 1 handed out for filling, 2 submitted, 3 output lent to the caller */
+    };
+    std::vector<stream_slot> ss;
+    hipStream_t s_h2d = nullptr, s_d2h = nullptr;
+    h2y_desc s_desc;
+    size_t s_plane_al = 0;
+    int s_head = 0, s_tail = 0, s_lent = -1;
+    bool streaming = false;
+    int slot_base = 0; /* run_frames(): first entry of d_frames/h_frames to use (one per stream slot) */
     /* pending batch */
     bool pending = false;
     h2y_desc p_desc;
@@ -322,16 +338,16 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
                 io.tmp_cb = ctx->d_tmp + ((size_t)half * kFirSubBatch + i) * 2 * npix;
                 io.tmp_cr = io.tmp_cb + npix;
             }
-            ctx->h_frames[f0 + i] = io;
+            ctx->h_frames[ctx->slot_base + f0 + i] = io;
         }
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frames + f0, ctx->h_frames + f0, nf * sizeof(frame_io), hipMemcpyHostToDevice,
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frames + ctx->slot_base + f0, ctx->h_frames + ctx->slot_base + f0, nf * sizeof(frame_io), hipMemcpyHostToDevice,
                                     ctx->stream));
         const int grid = grid_for(ctx, var, (uint64_t)g.chunks * nf);
         const int waves = h2y_fused_threads(var) / 64; /* the fused kernels leave one min/max record per wave */
         int rc = ensure(ctx, ctx->d_partial, ctx->partial_cap, (size_t)nf * grid * waves * 6 * sizeof(float));
         if (rc) return rc;
         fused_args a;
-        a.frames = ctx->d_frames + f0;
+        a.frames = ctx->d_frames + ctx->slot_base + f0;
         a.n_frames = nf;
         a.width = d->width;
         a.height = d->height;
@@ -371,7 +387,7 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
             HIP_TRY(ctx, hipEventRecord(ctx->ev_fused[half], ctx->stream));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->fir_stream, ctx->ev_fused[half], 0));
             fir_args fr;
-            fr.frames = ctx->d_frames + f0;
+            fr.frames = ctx->d_frames + ctx->slot_base + f0;
             fr.n_frames = nf;
             fr.src_cb = fr.src_cr = nullptr;
             fr.dst_cb = fr.dst_cr = nullptr;
@@ -568,6 +584,7 @@ void h2y_ctx_destroy(h2y_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->streaming) (void)h2y_stream_close(ctx);
     for (int i = 0; i < kMaxEvents; i++) {
         if (ctx->ev[i][0]) (void)hipEventDestroy(ctx->ev[i][0]);
         if (ctx->ev[i][1]) (void)hipEventDestroy(ctx->ev[i][1]);
@@ -770,6 +787,156 @@ int h2y_convert_frame(h2y_ctx *ctx, const h2y_desc *d, const void *const in_plan
     ctx->last_launches = ctx->n_ev;
     return H2Y_OK;
 }
+
+/* ---- streaming pipeline ------------------------------------------------------
+ * H2D of frame k+1, conversion of frame k and D2H of frame k-1 overlap: three streams, a ring of
+ * pinned host slots the caller fills and drains in place.  Every frame is converted in the
+ * reference's order (pic_stats pre-pass on the device, then the pixel kernel with its result in
+ * device memory): no speculation, nothing to redo, no host round trip between the stages. */
+static void stream_free(h2y_ctx *ctx)
+{
+    for (auto &s : ctx->ss) {
+        if (s.h_in) (void)hipHostFree(s.h_in);
+        if (s.h_out) (void)hipHostFree(s.h_out);
+        if (s.d_in) (void)hipFree(s.d_in);
+        if (s.d_out) (void)hipFree(s.d_out);
+        if (s.ev_h2d) (void)hipEventDestroy(s.ev_h2d);
+        if (s.ev_conv) (void)hipEventDestroy(s.ev_conv);
+        if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+    }
+    ctx->ss.clear();
+    if (ctx->s_h2d) (void)hipStreamDestroy(ctx->s_h2d);
+    if (ctx->s_d2h) (void)hipStreamDestroy(ctx->s_d2h);
+    ctx->s_h2d = ctx->s_d2h = nullptr;
+    ctx->streaming = false;
+    ctx->s_head = ctx->s_tail = 0;
+    ctx->s_lent = -1;
+}
+
+int h2y_stream_open(h2y_ctx *ctx, const h2y_desc *d, int depth)
+{
+    if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
+    if (ctx->pending || ctx->streaming) return fail(ctx, H2Y_EINVAL, "a batch is pending or a stream is already open");
+    const char *why;
+    int rc = h2y_desc_check(d, &why);
+    if (rc) return fail(ctx, rc, "descriptor: %s", why);
+    if (depth < 2 || depth > 16) return fail(ctx, H2Y_EINVAL, "depth must be 2..16");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    rc = reserve_batch(ctx, 64);
+    if (rc) return rc;
+    const size_t pb = h2y_plane_bytes(d), ob = h2y_frame_bytes(d);
+    ctx->s_plane_al = (pb + 255) & ~(size_t)255;
+    ctx->s_desc = *d;
+    ctx->ss.assign(depth, h2y_ctx::stream_slot());
+    ctx->streaming = true;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->s_h2d, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->s_d2h, hipStreamNonBlocking);
+    for (auto &s : ctx->ss) {
+        if (e == hipSuccess) e = hipHostMalloc((void **)&s.h_in, 3 * ctx->s_plane_al, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipHostMalloc((void **)&s.h_out, ob, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc((void **)&s.d_in, 3 * ctx->s_plane_al);
+        if (e == hipSuccess) e = hipMalloc((void **)&s.d_out, ob);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev_h2d, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev_conv, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming);
+    }
+    if (e != hipSuccess) {
+        stream_free(ctx);
+        return fail(ctx, H2Y_ENOMEM, "stream buffers: %s", hipGetErrorString(e));
+    }
+    return H2Y_OK;
+}
+
+int h2y_stream_input(h2y_ctx *ctx, void *planes[3])
+{
+    if (!ctx || !planes) return fail(ctx, H2Y_EINVAL, "null argument");
+    if (!ctx->streaming) return fail(ctx, H2Y_EINVAL, "no stream open");
+    h2y_ctx::stream_slot &s = ctx->ss[ctx->s_tail];
+    if (s.state == 1) { /* asked twice without a submit: same buffers again */
+    } else if (s.state != 0) return fail(ctx, H2Y_EINVAL, "all %d slots are in flight: take an output first", (int)ctx->ss.size());
+    s.state = 1;
+    for (int c = 0; c < 3; c++) planes[c] = s.h_in + c * ctx->s_plane_al;
+    return H2Y_OK;
+}
+
+int h2y_stream_submit(h2y_ctx *ctx)
+{
+    if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
+    if (!ctx->streaming) return fail(ctx, H2Y_EINVAL, "no stream open");
+    const int slot = ctx->s_tail;
+    h2y_ctx::stream_slot &s = ctx->ss[slot];
+    if (s.state != 1) return fail(ctx, H2Y_EINVAL, "nothing to submit: call h2y_stream_input first");
+    const h2y_desc *d = &ctx->s_desc;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t pb = h2y_plane_bytes(d), ob = h2y_frame_bytes(d);
+    frame_io io;
+    for (int c = 0; c < 3; c++) {
+        io.in[c] = s.d_in + c * ctx->s_plane_al;
+        HIP_TRY(ctx, hipMemcpyAsync(s.d_in + c * ctx->s_plane_al, s.h_in + c * ctx->s_plane_al, pb, hipMemcpyHostToDevice, ctx->s_h2d));
+    }
+    io.out = s.d_out;
+    io.tmp_cb = io.tmp_cr = nullptr;
+    HIP_TRY(ctx, hipEventRecord(s.ev_h2d, ctx->s_h2d));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, s.ev_h2d, 0));
+    const bool needs_stats = d->src_transfer != d->dst_transfer;
+    int rc;
+    if (needs_stats && !d->stats_override) {
+        rc = run_stats(ctx, d, io.in, (int)ctx->frames_cap, ctx->d_assumed); /* published in device memory, read by the next kernel */
+        if (rc) return rc;
+    } else {
+        /* the same six integers for every frame of the stream: staged once per slot, so an earlier copy still in flight reads its own */
+        assumed_stats *as = reinterpret_cast<assumed_stats *>(s.h_out); /* the slot's pinned output is idle until its D2H */
+        for (int c = 0; c < 3; c++) {
+            as->floor_[c] = d->stats_override ? d->floor[c] : 0;
+            as->ceil_[c] = d->stats_override ? d->ceiling[c] : 1;
+        }
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_assumed, as, sizeof *as, hipMemcpyHostToDevice, ctx->stream));
+    }
+    ctx->slot_base = slot;
+    ctx->n_ev = 0;
+    rc = run_frames(ctx, d, &io, 1, ctx->d_assumed, nullptr, false, slot, false);
+    ctx->slot_base = 0;
+    if (rc) return rc;
+    HIP_TRY(ctx, hipEventRecord(s.ev_conv, ctx->stream));
+    HIP_TRY(ctx, hipStreamWaitEvent(ctx->s_d2h, s.ev_conv, 0));
+    HIP_TRY(ctx, hipMemcpyAsync(s.h_out, s.d_out, ob, hipMemcpyDeviceToHost, ctx->s_d2h));
+    HIP_TRY(ctx, hipEventRecord(s.ev_done, ctx->s_d2h));
+    s.state = 2;
+    ctx->s_tail = (slot + 1) % (int)ctx->ss.size();
+    return H2Y_OK;
+}
+
+int h2y_stream_output(h2y_ctx *ctx, const uint16_t **yuv)
+{
+    if (!ctx || !yuv) return fail(ctx, H2Y_EINVAL, "null argument");
+    if (!ctx->streaming) return fail(ctx, H2Y_EINVAL, "no stream open");
+    if (ctx->s_lent >= 0) { /* the frame handed out last time goes back into the ring */
+        ctx->ss[ctx->s_lent].state = 0;
+        ctx->s_lent = -1;
+    }
+    h2y_ctx::stream_slot &s = ctx->ss[ctx->s_head];
+    if (s.state != 2) return fail(ctx, H2Y_EINVAL, "no submitted frame is waiting");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipEventSynchronize(s.ev_done));
+    *yuv = s.h_out;
+    s.state = 3;
+    ctx->s_lent = ctx->s_head;
+    ctx->s_head = (ctx->s_head + 1) % (int)ctx->ss.size();
+    return H2Y_OK;
+}
+
+int h2y_stream_close(h2y_ctx *ctx)
+{
+    if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
+    if (!ctx->streaming) return H2Y_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    (void)hipStreamSynchronize(ctx->s_h2d);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->s_d2h);
+    stream_free(ctx);
+    return H2Y_OK;
+}
+
 
 int h2y_pic_stats(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3], float fminmax[6], int32_t floor_ceiling[6])
 {

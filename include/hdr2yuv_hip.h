@@ -172,6 +172,28 @@ int h2y_subsample_420(h2y_ctx *ctx, int width, int height, int bit_depth,
                       int chroma_resampler_type, const uint16_t *d_src,
                       uint16_t *d_dst);
 
+/* ---- host <-> device pipeline --------------------------------------------
+ * The reference reads a frame, converts it and appends it to the .yuv, one after the other
+ * (hdr2yuv.cpp:582-656 reader, :797-928, tiff.cpp:457-551 writer).  Here the upload of frame
+ * k+1, the conversion of frame k and the download of frame k-1 overlap, through a ring of
+ * `depth` pinned host slots that the caller fills and drains in place:
+ *
+ *     h2y_stream_open(ctx, &desc, 3);
+ *     for each frame:  h2y_stream_input(ctx, planes);   read the file into planes[0..2]
+ *                      h2y_stream_submit(ctx);
+ *                      if (frames in flight == depth - 1) { h2y_stream_output(ctx, &yuv); write yuv; }
+ *     drain:           h2y_stream_output(ctx, &yuv) for the frames still in flight
+ *     h2y_stream_close(ctx);
+ *
+ * planes[c] hold h2y_plane_bytes() each, yuv h2y_frame_bytes(); the pointer h2y_stream_output
+ * returns stays valid until the next h2y_stream_output / h2y_stream_close.  Frames come out in
+ * submission order.  No other entry of the context may be used while a stream is open. */
+int h2y_stream_open(h2y_ctx *ctx, const h2y_desc *d, int depth /* 2..16 slots */);
+int h2y_stream_input(h2y_ctx *ctx, void *planes[3]);
+int h2y_stream_submit(h2y_ctx *ctx);
+int h2y_stream_output(h2y_ctx *ctx, const uint16_t **yuv);
+int h2y_stream_close(h2y_ctx *ctx);
+
 /* Timing of the last h2y_convert_batch*() call measured with HIP events on
  * the stream the kernels ran on: total ms over the main kernels and how many
  * launches that covered. */

@@ -462,3 +462,39 @@ def test_batch_redo_lists_across_frames(ctx, oracle, depth, mat, chroma, res):
         got = dev_out[f].cpu().numpy().view(np.uint16)
         want = oracle.convert_frame(od, host[f])
         assert np.array_equal(got, want), f"frame {f}: {np.count_nonzero(got != want)} samples differ"
+
+
+@pytest.mark.parametrize("res,depth_out", [(0, 12), (1, 10)])
+def test_stream_pipeline(oracle, res, depth_out):
+    """frames through the pinned ring (upload / convert / download overlapped) come out in
+    order and byte-identical; frames with different statistics follow each other (no speculation here)."""
+    rng = np.random.default_rng(99 + res)
+    w, hh = 320, 64
+    d = h.make_desc(w, hh, dst_depth=depth_out, dst_matrix=h.MATRIX_BT2020NC, resampler=res)
+    od = _to_oracle_desc(d)
+    frames = [_rand_planes(rng, w, hh, h.SAMPLE_F32) for _ in range(7)]
+    frames[3][1][5] = np.float32(2.5)  # ceiling 2 for this one only
+    c = h.Context(0)
+    try:
+        c.stream_open(d, 3)
+        got, inflight = [], 0
+        for fr in frames:
+            dst = c.stream_input()
+            for k in range(3):
+                dst[k][:] = fr[k]
+            c.stream_submit()
+            inflight += 1
+            if inflight == 2:
+                got.append(c.stream_output().copy())
+                inflight -= 1
+        while inflight:
+            got.append(c.stream_output().copy())
+            inflight -= 1
+        c.stream_close()
+        assert len(got) == len(frames)
+        for k, fr in enumerate(frames):
+            assert np.array_equal(got[k], oracle.convert_frame(od, fr)), f"frame {k}"
+        # the context is usable again afterwards
+        assert np.array_equal(c.convert_frame(d, frames[0]), got[0])
+    finally:
+        c.close()

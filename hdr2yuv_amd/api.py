@@ -28,7 +28,7 @@ EXPORTS = [
     "h2y_abi_version", "h2y_frame_bytes", "h2y_plane_bytes", "h2y_desc_check", "h2y_ctx_create", "h2y_ctx_destroy",
     "h2y_last_error", "h2y_ctx_set_stream", "h2y_convert_frame", "h2y_convert_batch", "h2y_convert_batch_enqueue",
     "h2y_batch_finish", "h2y_pic_stats", "h2y_matrix_convert", "h2y_subsample_420", "h2y_last_kernel_ms", "h2y_last_kernel_name",
-    "h2y_stream_open", "h2y_stream_input", "h2y_stream_submit", "h2y_stream_output", "h2y_stream_close",
+    "h2y_matrix_inverse", "h2y_stream_open", "h2y_stream_input", "h2y_stream_submit", "h2y_stream_output", "h2y_stream_close",
 ]
 
 
@@ -135,6 +135,8 @@ def load_library():
     L.h2y_matrix_convert.argtypes = [C.c_void_p, C.POINTER(H2YDesc), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.h2y_subsample_420.restype = C.c_int
     L.h2y_subsample_420.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.h2y_matrix_inverse.restype = C.c_int
+    L.h2y_matrix_inverse.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.h2y_stream_open.restype = C.c_int
     L.h2y_stream_open.argtypes = [C.c_void_p, C.POINTER(H2YDesc), C.c_int]
     L.h2y_stream_input.restype = C.c_int
@@ -264,6 +266,12 @@ class Context:
         n = C.c_int()
         self.lib.h2y_last_kernel_ms(self.h, C.byref(ms), C.byref(n))
         return ms.value, n.value
+
+    def matrix_inverse(self, width, height, in_depth, in_full_range, in_matrix, out_depth, in_planes, out_planes) -> None:
+        """Device U16 4:4:4 planes (Y, Cb/Dz, Cr/Dx) -> device U16 planes (G, B, R)."""
+        ip = (C.c_void_p * 3)(*[self._ptr(p) for p in in_planes])
+        op = (C.c_void_p * 3)(*[self._ptr(p) for p in out_planes])
+        self._check(self.lib.h2y_matrix_inverse(self.h, width, height, in_depth, in_full_range, in_matrix, out_depth, ip, op))
 
     # ---- host <-> device pipeline -----------------------------------------------------------
     def stream_open(self, d, depth=3) -> None:

@@ -788,6 +788,47 @@ int h2y_convert_frame(h2y_ctx *ctx, const h2y_desc *d, const void *const in_plan
     return H2Y_OK;
 }
 
+int h2y_matrix_inverse(h2y_ctx *ctx, int width, int height, int in_bit_depth, int in_full_range, int in_matrix_coeffs,
+                       int out_bit_depth, const uint16_t *const d_in[3], uint16_t *const d_out[3])
+{
+    if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
+    if (ctx->pending || ctx->streaming) return fail(ctx, H2Y_EINVAL, "a batch is pending or a stream is open");
+    if (width < 1 || height < 1 || (uint64_t)width * height >= (1ull << 28)) return fail(ctx, H2Y_EINVAL, "bad picture size");
+    if (in_bit_depth < 8 || in_bit_depth > 16 || out_bit_depth < 8 || out_bit_depth > 16) return fail(ctx, H2Y_EINVAL, "bit depths must be 8..16");
+    if (in_matrix_coeffs == H2Y_MATRIX_GBR) /* convert.cpp:1733-1736: "Can't determine color difference to use?" and exit(0) */
+        return fail(ctx, H2Y_EUNSUPPORTED, "matrix_coeffs 0 (GBR) has no inverse in the reference (it exits)");
+    if (!d_in || !d_out) return fail(ctx, H2Y_EINVAL, "null pointer arrays");
+    inverse_args a;
+    for (int c = 0; c < 3; c++) {
+        if (!d_in[c] || !d_out[c] || ((uintptr_t)d_in[c] & 7) || ((uintptr_t)d_out[c] & 7))
+            return fail(ctx, H2Y_EINVAL, "plane %d is null or not 8-byte aligned", c);
+        a.in[c] = d_in[c];
+        a.out[c] = d_out[c];
+    }
+    const clip_limits ic = make_clip(in_bit_depth, in_full_range);
+    a.npix = (uint32_t)width * (uint32_t)height;
+    a.d709 = in_matrix_coeffs == H2Y_MATRIX_BT709;
+    a.minVR = ic.minVR;
+    a.maxVR = ic.maxVR;
+    a.shift_right = in_bit_depth > out_bit_depth;
+    a.shift = a.shift_right ? in_bit_depth - out_bit_depth : out_bit_depth - in_bit_depth;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint32_t blocks = (a.npix / 4 + 255) / 256;
+    if (blocks > (uint32_t)ctx->n_cu * 16u) blocks = (uint32_t)ctx->n_cu * 16u;
+    if (blocks < 1) blocks = 1;
+    ctx->n_ev = 0;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[0][0], ctx->stream));
+    HIP_TRY(ctx, h2y_launch_inverse((int)blocks, ctx->stream, a));
+    HIP_TRY(ctx, hipEventRecord(ctx->ev[0][1], ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0][0], ctx->ev[0][1]));
+    ctx->last_ms = ms;
+    ctx->last_launches = 1;
+    ctx->last_name = "k_inverse";
+    return H2Y_OK;
+}
+
 /* ---- streaming pipeline ------------------------------------------------------
  * H2D of frame k+1, conversion of frame k and D2H of frame k-1 overlap: three streams, a ring of
  * pinned host slots the caller fills and drains in place.  Every frame is converted in the

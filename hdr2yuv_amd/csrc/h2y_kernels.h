@@ -102,6 +102,15 @@ struct fir_args {
     h2y::pix_params pp;
 };
 
+struct inverse_args {
+    const void *in[3]; /* Y, Cb/Dz, Cr/Dx: U16 4:4:4 planes, 8-byte aligned */
+    void *out[3];      /* G, B, R */
+    uint32_t npix;
+    int d709;          /* matrix_coeffs == 1 */
+    uint32_t minVR, maxVR;
+    int shift, shift_right;
+};
+
 int h2y_fused_threads(const fused_variant &v);
 const char *h2y_fused_name(const fused_variant &v);
 int h2y_fused_blocks_per_cu(const fused_variant &v);
@@ -110,6 +119,7 @@ hipError_t h2y_launch_build_lut16(hipStream_t st, const void *table, float *lut)
 hipError_t h2y_launch_stats(int in_kind, int grid, hipStream_t st, const stats_args &a);
 hipError_t h2y_launch_stats_final(int n_frames, hipStream_t st, const final_args &a);
 hipError_t h2y_launch_fir420(hipStream_t st, const fir_args &a);
+hipError_t h2y_launch_inverse(int grid, hipStream_t st, const inverse_args &a);
 hipError_t h2y_launch_box420(hipStream_t st, const uint16_t *src, uint16_t *dst, int W, int H);
 
 #endif

@@ -1250,6 +1250,72 @@ __global__ __launch_bounds__(256) void k_fir420(fir_args a)
     }
 }
 
+/*
+ * k_inverse: matrix_inverse(), convert.cpp:1320-1867, U16 4:4:4 Y'CbCr / Y'DzDx -> U16 G,B,R planes
+ * (the .yuv -> .tiff flow, hdr2yuv.cpp:818-819).  Elementwise, 12 B/px, HBM-bound.  One thread = four
+ * consecutive samples of each plane (8-byte loads and stores), grid-stride.  The arithmetic is the
+ * reference's, operation by operation and type by type, with the behaviour of the compiled function:
+ * Half = 2048 and Full = 4096 at every bit depth; only matrix_coeffs 1 takes the BT.709 equations
+ * (the test at convert.cpp:1391 compares matrix_coeffs with booleans), everything else Y'DzDx; the
+ * video-range clamp always runs, with the input picture's limits.
+ */
+__device__ __forceinline__ void inverse_pixel(const inverse_args &a, uint32_t y, uint32_t cb, uint32_t cr, uint32_t &G, uint32_t &B, uint32_t &R)
+{
+    float Yav = (float)y;
+    const float Cb = (float)cb, Cr = (float)cr;
+    float Rp, Bp;
+    if (!a.d709) {
+        Rp = (float)((2.0 * (double)Cr - 4095.0) + (double)Yav);
+        Bp = (float)((2.0 * (double)Cb - 4095.0) + (double)Yav);
+    } else {
+        float t = (float)(((double)Cb - 2047.5) * 1.8556 + (double)Yav);
+        if (t > 4095.0f) t = 4095.0f;
+        Bp = t;
+        t = (float)(((double)Cr - 2047.5) * 1.5748 + (double)Yav);
+        if (t > 4095.0f) t = 4095.0f;
+        Rp = t;
+        t = (float)((((double)Yav - 0.07222 * (double)Bp) - 0.2126 * (double)Rp) / 0.7152 + 0.5);
+        if (t > 4095.0f) t = 4095.0f;
+        Yav = t;
+    }
+    int g = sat_i32_f32(Yav), b = sat_i32_f32(Bp), r = sat_i32_f32(Rp);
+    /* negative -> 0, then the clamp to [minVR, maxVR] (minVR >= 0): one clamp does both */
+    g = min(max(g, (int)a.minVR), (int)a.maxVR);
+    b = min(max(b, (int)a.minVR), (int)a.maxVR);
+    r = min(max(r, (int)a.minVR), (int)a.maxVR);
+    if (a.shift_right) { g >>= a.shift; b >>= a.shift; r >>= a.shift; }
+    else { g <<= a.shift; b <<= a.shift; r <<= a.shift; }
+    G = (uint32_t)g & 0xFFFFu; /* stored into an unsigned short */
+    B = (uint32_t)b & 0xFFFFu;
+    R = (uint32_t)r & 0xFFFFu;
+}
+__global__ __launch_bounds__(256) void k_inverse(inverse_args a)
+{
+    const uint32_t n4 = a.npix >> 2;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+        const u32x2 y = gload<u32x2>(a.in[0], i), cb = gload<u32x2>(a.in[1], i), cr = gload<u32x2>(a.in[2], i);
+        uint32_t G[4], B[4], R[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t wy = j & 2 ? y.y : y.x, wb = j & 2 ? cb.y : cb.x, wr = j & 2 ? cr.y : cr.x;
+            inverse_pixel(a, j & 1 ? wy >> 16 : wy & 0xFFFFu, j & 1 ? wb >> 16 : wb & 0xFFFFu, j & 1 ? wr >> 16 : wr & 0xFFFFu, G[j], B[j], R[j]);
+        }
+        gstore<u32x2>(a.out[0], i, u32x2{G[0] | (G[1] << 16), G[2] | (G[3] << 16)});
+        gstore<u32x2>(a.out[1], i, u32x2{B[0] | (B[1] << 16), B[2] | (B[3] << 16)});
+        gstore<u32x2>(a.out[2], i, u32x2{R[0] | (R[1] << 16), R[2] | (R[3] << 16)});
+    }
+    /* the last npix % 4 samples */
+    const uint32_t tail = a.npix & 3u;
+    if (blockIdx.x == 0 && threadIdx.x < tail) {
+        const uint32_t i = (n4 << 2) + threadIdx.x;
+        uint32_t G, B, R;
+        inverse_pixel(a, gload<uint16_t>(a.in[0], i), gload<uint16_t>(a.in[1], i), gload<uint16_t>(a.in[2], i), G, B, R);
+        gstore<uint16_t>(a.out[0], i, (uint16_t)G);
+        gstore<uint16_t>(a.out[1], i, (uint16_t)B);
+        gstore<uint16_t>(a.out[2], i, (uint16_t)R);
+    }
+}
+
 /* ---- launch helpers (called from h2y_api.hip) --------------------------- */
 typedef void (*fused_fn)(fused_args);
 
@@ -1361,6 +1427,12 @@ hipError_t h2y_launch_stats(int in_kind, int grid, hipStream_t st, const stats_a
 hipError_t h2y_launch_stats_final(int n_frames, hipStream_t st, const final_args &a)
 {
     hipLaunchKernelGGL(k_stats_final, dim3(n_frames), dim3(256), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t h2y_launch_inverse(int grid, hipStream_t st, const inverse_args &a)
+{
+    hipLaunchKernelGGL(k_inverse, dim3(grid), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 

@@ -172,6 +172,18 @@ int h2y_subsample_420(h2y_ctx *ctx, int width, int height, int bit_depth,
                       int chroma_resampler_type, const uint16_t *d_src,
                       uint16_t *d_dst);
 
+/* matrix_inverse() (hdr.h:423, convert.cpp:1320-1867): the .yuv -> .tiff flow of
+ * hdr2yuv.cpp:818-819.  U16 4:4:4 planes Y', Cb/Dz, Cr/Dx in, U16 planes G, B, R out, on the device,
+ * 8-byte aligned.  Byte-exact with the compiled reference, including its oddities: Half/Full are those
+ * of 12 bits at any bit depth, only matrix_coeffs 1 (BT.709) takes the Y'CbCr equations -- every other
+ * value, BT.2020 included, the Y'DzDx ones --, matrix_coeffs 0 is refused (the reference exits), the
+ * result is clamped to the INPUT picture's video (or full) range and shifted to out_bit_depth.
+ * 4:2:0 input has no defined result in the reference (it indexes all planes at full resolution;
+ * Subsample420to444 is compiled out): upsample first. */
+int h2y_matrix_inverse(h2y_ctx *ctx, int width, int height, int in_bit_depth, int in_full_range,
+                       int in_matrix_coeffs, int out_bit_depth, const uint16_t *const d_in[3],
+                       uint16_t *const d_out[3]);
+
 /* ---- host <-> device pipeline --------------------------------------------
  * The reference reads a frame, converts it and appends it to the .yuv, one after the other
  * (hdr2yuv.cpp:582-656 reader, :797-928, tiff.cpp:457-551 writer).  Here the upload of frame

@@ -118,8 +118,24 @@ class Oracle:
         L.h2y_oracle_matrix_convert.argtypes = [C.POINTER(H2YDesc), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p,
                                                 C.c_int, C.POINTER(C.c_void_p)]
 
+        L.h2y_oracle_matrix_inverse.restype = C.c_int
+        L.h2y_oracle_matrix_inverse.argtypes = [C.c_int] * 6 + [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        self._inverse_fn = L.h2y_oracle_matrix_inverse
+
     def pq(self, x: float) -> float:
         return float(self.lib.h2y_oracle_pq10000_r(float(x)))
+
+    def matrix_inverse(self, width, height, in_depth, in_full_range, in_matrix, out_depth, planes):
+        """matrix_inverse() on three U16 4:4:4 planes (Y, Cb/Dz, Cr/Dx) -> (G, B, R) planes."""
+        n = width * height
+        src = [np.ascontiguousarray(p, dtype=np.uint16).reshape(-1) for p in planes]
+        dst = [np.empty(n, dtype=np.uint16) for _ in range(3)]
+        ip = (C.c_void_p * 3)(*[p.ctypes.data for p in src])
+        op = (C.c_void_p * 3)(*[p.ctypes.data for p in dst])
+        rc = self._inverse_fn(width, height, in_depth, in_full_range, in_matrix, out_depth, ip, op)
+        if rc != 0:
+            raise RuntimeError(f"matrix_inverse rc={rc}")
+        return dst
 
     def convert_frame(self, d: H2YDesc, planes) -> np.ndarray:
         out = np.empty(frame_samples(d), dtype=np.uint16)
@@ -193,6 +209,9 @@ class Ref:
         L.h2y_ref_convert_frame.restype = C.c_int
         L.h2y_ref_convert_frame.argtypes = [C.POINTER(H2YDesc), C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p]
         L.h2y_ref_sub420.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.h2y_ref_matrix_inverse.restype = C.c_int
+        L.h2y_ref_matrix_inverse.argtypes = [C.c_int] * 6 + [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        self._inverse_fn = L.h2y_ref_matrix_inverse
 
     def pq(self, x: float) -> float:
         return float(self.lib.h2y_ref_pq10000_r(float(x)))
@@ -212,6 +231,18 @@ class Ref:
         src = np.ascontiguousarray(src, dtype=np.uint16)
         dst = np.empty((h >> 1, w >> 1), dtype=np.uint16)
         self.lib.h2y_ref_sub420(src.ctypes.data, dst.ctypes.data, w, h, bit_depth, 1 if fir else 0)
+        return dst
+
+    def matrix_inverse(self, width, height, in_depth, in_full_range, in_matrix, out_depth, planes):
+        """matrix_inverse() on three U16 4:4:4 planes (Y, Cb/Dz, Cr/Dx) -> (G, B, R) planes."""
+        n = width * height
+        src = [np.ascontiguousarray(p, dtype=np.uint16).reshape(-1) for p in planes]
+        dst = [np.empty(n, dtype=np.uint16) for _ in range(3)]
+        ip = (C.c_void_p * 3)(*[p.ctypes.data for p in src])
+        op = (C.c_void_p * 3)(*[p.ctypes.data for p in dst])
+        rc = self._inverse_fn(width, height, in_depth, in_full_range, in_matrix, out_depth, ip, op)
+        if rc != 0:
+            raise RuntimeError(f"matrix_inverse rc={rc}")
         return dst
 
 

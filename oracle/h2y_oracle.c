@@ -505,3 +505,63 @@ int h2y_oracle_convert_frame(const h2y_desc *d, const void *const in_planes[3], 
     for (int c = 0; c < 3; c++) { free(tmp[c]); free(wide[c]); }
     return rc;
 }
+
+/* ---- matrix_inverse, convert.cpp:1320-1867 -------------------------------------------------
+ * What the compiled function does, oddities included:
+ *  - Half = 2048 and Full = 4096 whatever the bit depth (convert.cpp:1337-1338);
+ *  - "DXYZ = 0" is decided by comparing matrix_coeffs with the BOOLEANS D709, D2020, Y100, Y500
+ *    (convert.cpp:1391): true for matrix 1 (BT.709, D709 == 1) and matrix 0 (== Y100 == 0) only, so
+ *    BT.2020 pictures take the Y'DzDx formula like everything else; matrix 0 ends in exit(0)
+ *    (convert.cpp:1733-1736);
+ *  - 0.07222 (sic) in the BT.709 green, convert.cpp:1676;
+ *  - the video-range clamp always runs, with the INPUT picture's limits (FULLRANGE is a constant 0,
+ *    convert.cpp:1343,1783-1793): for a full-range input those limits are 0 and maxCV. */
+int h2y_oracle_matrix_inverse(int width, int height, int in_bit_depth, int in_full_range, int in_matrix, int out_bit_depth,
+                              const uint16_t *const in_planes[3], uint16_t *const out_planes[3])
+{
+    const unsigned short Half = 2048, Full = 4096;
+    h2y_oracle_clip clip;
+    h2y_oracle_set_clip(in_bit_depth, in_full_range, &clip);
+    const int d709 = in_matrix == 1;
+    if (in_matrix == 0) return 1;
+    const size_t n = (size_t)width * height;
+    for (size_t i = 0; i < n; i++) {
+        float Yav = (float)in_planes[0][i], Cb = (float)in_planes[1][i], Cr = (float)in_planes[2][i];
+        float Rp, Bp, tmpF;
+        if (!d709) {
+            Rp = (float)(2.0 * Cr - (Full - 1.0) + Yav);
+            Bp = (float)(2.0 * Cb - (Full - 1.0) + Yav);
+        } else {
+            tmpF = (float)(((float)(Cb) - (Half - 0.5)) * 1.8556 + Yav);
+            if (tmpF > (Full - 1.0)) tmpF = (float)(Full - 1.0);
+            Bp = tmpF;
+            tmpF = (float)(((float)(Cr) - (Half - 0.5)) * 1.5748 + Yav);
+            if (tmpF > (Full - 1.0)) tmpF = (float)(Full - 1.0);
+            Rp = tmpF;
+            tmpF = (float)(((float)Yav - 0.07222 * (float)Bp - 0.2126 * (float)Rp) / 0.7152 + 0.5);
+            if (tmpF > (Full - 1.0)) tmpF = (float)(Full - 1.0);
+            Yav = tmpF;
+        }
+        int G = (int)Yav, B = (int)Bp, R = (int)Rp;
+        if (G < 0) G = 0;
+        if (R < 0) R = 0;
+        if (B < 0) B = 0;
+        R = (R < clip.minVR) ? clip.minVR : R;
+        G = (G < clip.minVR) ? clip.minVR : G;
+        B = (B < clip.minVR) ? clip.minVR : B;
+        R = (R > clip.maxVR) ? clip.maxVR : R;
+        G = (G > clip.maxVR) ? clip.maxVR : G;
+        B = (B > clip.maxVR) ? clip.maxVR : B;
+        if (in_bit_depth > out_bit_depth) {
+            int shift = in_bit_depth - out_bit_depth;
+            R = R >> shift; G = G >> shift; B = B >> shift;
+        } else {
+            int shift = out_bit_depth - in_bit_depth;
+            R = R << shift; G = G << shift; B = B << shift;
+        }
+        out_planes[0][i] = (uint16_t)G;
+        out_planes[1][i] = (uint16_t)B;
+        out_planes[2][i] = (uint16_t)R;
+    }
+    return 0;
+}

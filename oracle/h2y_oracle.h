@@ -75,6 +75,11 @@ int h2y_oracle_convert_frame(const h2y_desc *d, const void *const in_planes[3],
 
 size_t h2y_oracle_frame_bytes(const h2y_desc *d);
 
+/* matrix_inverse, convert.cpp:1320-1867, U16 4:4:4 in -> U16 out (the .yuv -> .tiff flow, hdr2yuv.cpp:818-819).
+ * Returns 1 where the reference calls exit() (matrix_coeffs 0). */
+int h2y_oracle_matrix_inverse(int width, int height, int in_bit_depth, int in_full_range, int in_matrix, int out_bit_depth,
+                              const uint16_t *const in_planes[3], uint16_t *const out_planes[3]);
+
 /* The synthetic frame of SURVEY.md 8c/8d: LCG seeded per frame, planted 0.0
  * and 1.0.  sample_type F32 -> float planes; F16 -> half bit patterns. */
 void h2y_oracle_synth_plane_f32(float *plane, size_t n, uint32_t *lcg_state);

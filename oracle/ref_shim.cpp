@@ -51,6 +51,8 @@ float h2y_ref_pq10000_r(float L);
 int h2y_ref_convert_frame(const h2y_desc *d, const void *const in_planes[3], uint16_t *out_yuv,
                           uint16_t *tmp444_out /* optional: 3 planes of matrix_convert output */);
 int h2y_ref_sub420(const uint16_t *src, uint16_t *dst, int width, int height, int bit_depth, int fir);
+int h2y_ref_matrix_inverse(int width, int height, int in_bit_depth, int in_full_range, int in_matrix, int out_bit_depth,
+                           const uint16_t *const in_planes[3], uint16_t *const out_planes[3]);
 
 } // extern "C"
 
@@ -155,4 +157,31 @@ int h2y_ref_convert_frame(const h2y_desc *d, const void *const in_planes[3], uin
     deinit_pic(tmp_pic);
     deinit_pic(out_pic);
     return down_shift < 0 ? 1 : rc;
+}
+
+/* matrix_inverse() as main() reaches it for a .yuv -> .tiff run (hdr2yuv.cpp:803-819): in_pic is the
+ * 4:4:4 U16 picture read from the .yuv, tmp_pic has the input's buffer type and bit depth
+ * (hdr2yuv.cpp:805-808: same buffer types => tmp_bit_depth = in_pic->bit_depth) unless the caller asks
+ * for another output depth (the shift at convert.cpp:1800-1814 is what that exercises). */
+extern "C" int h2y_ref_matrix_inverse(int width, int height, int in_bit_depth, int in_full_range, int in_matrix, int out_bit_depth,
+                                      const uint16_t *const in_planes[3], uint16_t *const out_planes[3])
+{
+    MuteStdout mute;
+    static hdr_t h;
+    memset(&h, 0, sizeof(h));
+    pic_t *in_pic = &h.in_pic;
+    pic_t tmp_storage;
+    memset(&tmp_storage, 0, sizeof(tmp_storage));
+    pic_t *tmp_pic = &tmp_storage;
+    const size_t n = (size_t)width * height;
+    init_pic(in_pic, width, height, CHROMA_444, in_bit_depth, in_full_range, 1, 1, in_matrix, 0, PIC_TYPE_U16, 0, 0, "in_pic");
+    for (int c = 0; c < 3; c++) memcpy(in_pic->buf[c], in_planes[c], n * sizeof(uint16_t));
+    init_pic(tmp_pic, width, height, CHROMA_444, out_bit_depth, 0, 1, 1, 0, 0, PIC_TYPE_U16, 0, 0, "tmp_pic");
+    int rc = matrix_inverse(tmp_pic, &h, in_pic);
+    for (int c = 0; c < 3; c++) memcpy(out_planes[c], tmp_pic->buf[c], n * sizeof(uint16_t));
+    for (int c = 0; c < 3; c++) {
+        free(in_pic->buf[c]);
+        free(tmp_pic->buf[c]);
+    }
+    return rc;
 }

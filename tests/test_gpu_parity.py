@@ -498,3 +498,26 @@ def test_stream_pipeline(oracle, res, depth_out):
         assert np.array_equal(c.convert_frame(d, frames[0]), got[0])
     finally:
         c.close()
+
+
+def test_matrix_inverse(ctx, oracle):
+    """h2y_matrix_inverse vs the oracle (itself pinned to the reference's object code)."""
+    import torch
+
+    rng = np.random.default_rng(32)
+    for (w, hh) in ((256, 64), (67, 9)):
+        n = w * hh
+        for mat in (1, 9, 11):
+            for ind, outd, full in ((12, 16, 0), (12, 12, 0), (10, 16, 0), (12, 10, 1), (16, 16, 0)):
+                planes = [rng.integers(0, 1 << ind, n).astype(np.uint16) for _ in range(3)]
+                for p in planes:
+                    p[:5] = [0, (1 << ind) - 1, 1 << (ind - 1), (1 << (ind - 1)) - 1, 1]
+                din = [torch.from_numpy(p.view(np.int16)).cuda() for p in planes]
+                dout = [torch.zeros(n, dtype=torch.int16, device="cuda") for _ in range(3)]
+                ctx.matrix_inverse(w, hh, ind, full, mat, outd, din, dout)
+                want = oracle.matrix_inverse(w, hh, ind, full, mat, outd, planes)
+                for c in range(3):
+                    got = dout[c].cpu().numpy().view(np.uint16)
+                    assert np.array_equal(got, want[c]), (w, hh, mat, ind, outd, full, c, int(np.count_nonzero(got != want[c])))
+    with pytest.raises(h.H2YError):
+        ctx.matrix_inverse(256, 64, 12, 0, 0, 16, din, dout)  # GBR: the reference exits

@@ -131,3 +131,20 @@ def test_other_transfer_pairs_equal_reference(oracle, ref):
         for (mat, dep, ch, res) in ((ob.MATRIX_BT2020NC, 12, 1, 1), (ob.MATRIX_YDZDX, 16, 3, 0)):
             d = ob.make_desc(w, h, dst_depth=dep, src_transfer=src, dst_transfer=dst, dst_matrix=mat, chroma=ch, resampler=res)
             assert np.array_equal(oracle.convert_frame(d, planes), ref.convert_frame(d, planes)), (src, dst, mat)
+
+
+def test_matrix_inverse_restatement_equals_reference(oracle, ref):
+    """matrix_inverse() restated vs the reference's object code, every branch the compiled
+    function can take (matrix 1 = BT.709; 9, 10 (BT.2020) and 11 all take the Y'DzDx equations), bit-depth
+    shifts both ways, full and video range, extreme code values."""
+    rng = np.random.default_rng(31)
+    w, hh = 96, 20
+    for mat in (1, 9, 10, 11, 2):
+        for ind, outd, full in ((12, 16, 0), (12, 12, 0), (10, 16, 0), (12, 10, 1), (16, 16, 0), (14, 12, 0), (8, 8, 1)):
+            planes = [rng.integers(0, 1 << ind, w * hh).astype(np.uint16) for _ in range(3)]
+            for p in planes:
+                p[:5] = [0, (1 << ind) - 1, 1 << (ind - 1), (1 << (ind - 1)) - 1, 1]
+            a = oracle.matrix_inverse(w, hh, ind, full, mat, outd, planes)
+            b = ref.matrix_inverse(w, hh, ind, full, mat, outd, planes)
+            for c in range(3):
+                assert np.array_equal(a[c], b[c]), (mat, ind, outd, full, c)

@@ -72,6 +72,19 @@ def main():
         u = [[torch.from_numpy(rng.integers(0, 65536, w * hh, dtype=np.uint16).view(np.int16)).cuda() for _ in range(3)] for _ in range(F)]
         timeit(ctx, h.make_desc(w, hh, sample=h.SAMPLE_U16, src_depth=16, dst_depth=10, dst_matrix=9, resampler=0, src_transfer=16, dst_transfer=16), u,
                "4K u16 RGB -> 10-bit 2020nc 4:2:0 box, equal transfers", bytes_per_px=9.0)
+    if on("inv"):
+        # matrix_inverse, 4K 12-bit 4:4:4 BT.709 -> 16-bit G,B,R planes; 12 B/px
+        rng = np.random.default_rng(4)
+        n = w * hh
+        din = [torch.from_numpy(rng.integers(0, 4096, n, dtype=np.uint16).view(np.int16)).cuda() for _ in range(3)]
+        dout = [torch.empty(n, dtype=torch.int16, device="cuda") for _ in range(3)]
+        for mat, name in ((1, "BT.709"), (11, "YDzDx")):
+            ms = 0.0
+            for _ in range(10):
+                ctx.matrix_inverse(w, hh, 12, 0, mat, 16, din, dout)
+                ms += ctx.last_kernel_ms()[0]
+            ms /= 10
+            print(f"matrix_inverse 4K 12-bit {name:7s} -> 16-bit GBR   kernel {ms*1e3:8.1f} us/frame  {n/ms/1e6:8.1f} Gpx/s  {n*12/ms/1e6:7.0f} GB/s ({n*12/ms/1e6/80:.1f}% of 8TB/s)", flush=True)
     if on("c1"):
         w1, h1 = 1920, 1080
         s1 = [[torch.from_numpy(p).cuda() for p in synth_frame(w1, h1, k)] for k in range(F)]

@@ -1150,8 +1150,12 @@ __global__ __launch_bounds__(256) void k_box420(const uint16_t *__restrict__ src
  *   3. vertical 12-tap -> 4:2:0 sample, clamp, truncate, then shift + range
  *      clamp of write_yuv
  */
+#ifndef FIR_TW
 #define FIR_TW 64
+#endif
+#ifndef FIR_TH
 #define FIR_TH 32
+#endif
 #define FIR_ROWS (2 * FIR_TH + 10)
 #define FIR_COLS (2 * FIR_TW + 10)
 #define FIR_LCOLS (2 * FIR_TW + 16) /* staged columns: 8 left of the tile (16-byte aligned), 8 right */

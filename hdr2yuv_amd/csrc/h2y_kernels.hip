@@ -546,6 +546,26 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
     }
 }
 
+/* The branch-free loop forms (k_fused2, k_fused_t1, k_fused_lut16) ask for the next tile while they
+ * work on the current one.  Where does this block go after chunk k of frame f: chunk k + G of the same
+ * frame, else its first chunk of the next frame (k_next_frame), else nowhere -- then the current tile is
+ * simply asked for again (the request is unconditional).  Returns the next tile's position and which
+ * frame's planes to read; *have says whether the data requested is the tile the block meets next. */
+template <int THREADS>
+__device__ __forceinline__ tile_pos next_tile(const fused_args &a, int f, uint32_t k, uint32_t k_next_frame, const frame_io &io,
+                                              const frame_io &io_next, const void *(&src)[3], bool *have)
+{
+    const uint32_t G = gridDim.x;
+    uint32_t k2 = k + G;
+    const bool same = k2 < a.chunks_per_frame;
+    if (!same) k2 = k_next_frame;
+    *have = same || (f + 1 < a.n_frames && k2 < a.chunks_per_frame);
+    if (!*have) k2 = k;
+#pragma unroll
+    for (int c = 0; c < 3; c++) src[c] = (!same && *have) ? io_next.in[c] : io.in[c];
+    return tile_locate(umin32(k2 * THREADS + threadIdx.x, a.tiles_per_frame - 1u), a.width, a.height, a.wq, a.wq_magic);
+}
+
 /*
  * k_fused2: k_fused's work (binary64 tier for every sample) in the loop form of k_fused_t1 below --
  * row-wise tiles with rolling prefetch, one basic block of memory operations, no divergence around
@@ -599,15 +619,8 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
         for (; k < a.chunks_per_frame; k += G) {
             tile_pos t = t_cur;
             t.row1 = true;
-            uint32_t k2 = k + G;
-            const bool same = k2 < a.chunks_per_frame;
-            if (!same) k2 = k_next_frame;
-            have = same || (f + 1 < a.n_frames && k2 < a.chunks_per_frame);
-            if (!have) k2 = k;
-            const tile_pos t2 = tile_locate(umin32(k2 * H2Y_FUSED_THREADS + threadIdx.x, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
             const void *src[3];
-#pragma unroll
-            for (int c = 0; c < 3; c++) src[c] = (!same && have) ? io_next.in[c] : io.in[c];
+            const tile_pos t2 = next_tile<H2Y_FUSED_THREADS>(a, f, k, k_next_frame, io, io_next, src, &have);
 
             tile_out o;
             uint32_t sb[2], sr[2];
@@ -765,17 +778,8 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
                 const uint32_t tt = k * H2Y_T1_THREADS + threadIdx.x;
                 tile_pos t = t_cur; /* located one iteration ago, as the prefetch target */
                 t.row1 = true;
-                /* Where does this block go next: k + G in this frame, else its first chunk of the next frame.
-                 * When there is no next tile, this tile is simply asked for again. */
-                uint32_t k2 = k + G;
-                const bool same = k2 < a.chunks_per_frame;
-                if (!same) k2 = k_next_frame;
-                have = same || (f + 1 < a.n_frames && k2 < a.chunks_per_frame);
-                if (!have) k2 = k;
-                const tile_pos t2 = tile_locate(umin32(k2 * H2Y_T1_THREADS + threadIdx.x, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
                 const void *src[3];
-#pragma unroll
-                for (int c = 0; c < 3; c++) src[c] = (!same && have) ? io_next.in[c] : io.in[c];
+                const tile_pos t2 = next_tile<H2Y_T1_THREADS>(a, f, k, k_next_frame, io, io_next, src, &have);
 
                 tile_out o;
                 uint32_t sb[2], sr[2]; /* 2x2 box: chroma sums of the two blocks */
@@ -917,15 +921,8 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
         for (; k < a.chunks_per_frame; k += G) {
             tile_pos t = t_cur;
             t.row1 = true;
-            uint32_t k2 = k + G;
-            const bool same = k2 < a.chunks_per_frame;
-            if (!same) k2 = k_next_frame;
-            have = same || (f + 1 < a.n_frames && k2 < a.chunks_per_frame);
-            if (!have) k2 = k;
-            const tile_pos t2 = tile_locate(umin32(k2 * H2Y_FUSED_THREADS + threadIdx.x, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
             const void *src[3];
-#pragma unroll
-            for (int c = 0; c < 3; c++) src[c] = (!same && have) ? io_next.in[c] : io.in[c];
+            const tile_pos t2 = next_tile<H2Y_FUSED_THREADS>(a, f, k, k_next_frame, io, io_next, src, &have);
             tile_out o;
             uint32_t sb[2], sr[2];
 #pragma unroll

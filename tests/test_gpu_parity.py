@@ -521,3 +521,27 @@ def test_matrix_inverse(ctx, oracle):
                     assert np.array_equal(got, want[c]), (w, hh, mat, ind, outd, full, c, int(np.count_nonzero(got != want[c])))
     with pytest.raises(h.H2YError):
         ctx.matrix_inverse(256, 64, 12, 0, 0, 16, din, dout)  # GBR: the reference exits
+
+
+@pytest.mark.parametrize("name", ["C2_4k_2020_12b_box", "C2_4k_2020_12b_fir", "C3_4k_ydzdx_16b_444"])
+def test_full_size_batch_of_frames(ctx, oracle, name):
+    """One launch over three full-size frames (prefetch across frame boundaries, redo lists spanning
+    frames, FIR sub-batches): frame 0 is the SURVEY 8c known answer, frames 1 and 2 (generator seeds
+    12346, 12347) are checked against the oracle."""
+    import torch
+
+    case = KNOWN["cases"][name]
+    d = h.make_desc(**case["desc"])
+    host = [oracle.synth_frame(d.width, d.height, k) for k in range(3)]
+    dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in host]
+    nb = h.frame_bytes(d)
+    dev_out = [torch.zeros(nb // 2, dtype=torch.int16, device="cuda") for _ in host]
+    torch.cuda.synchronize()
+    ctx.convert_batch(d, dev_in, dev_out)
+    got0 = dev_out[0].cpu().numpy().view(np.uint16)
+    assert _md5(got0) == case["md5"]
+    od = _to_oracle_desc(d)
+    for f in (1, 2):
+        got = dev_out[f].cpu().numpy().view(np.uint16)
+        want = oracle.convert_frame(od, host[f])
+        assert np.array_equal(got, want), f"{name} frame {f}: {np.count_nonzero(got != want)} samples differ"

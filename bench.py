@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=32, help="frames per GPU per step (one launch covers them all)")
+    ap.add_argument("--frames", type=int, default=64, help="frames per GPU per step (one launch covers them all; 64 x 124 MB = 8 GB of the 288)")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--resampler", default="box", choices=["box", "fir"])
     ap.add_argument("--no-cpu-baseline", action="store_true")

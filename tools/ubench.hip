@@ -36,6 +36,38 @@ template <int OP> __device__ __forceinline__ void body(double (&d)[CHAINS], floa
         if (OP == 18) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(i[c]) : "v"(i[(c + 1) % CHAINS]) : "vcc");
         if (OP == 19) asm volatile("v_ldexp_f64 %0, %0, %1" : "+v"(d[c]) : "v"(i[c]));
         if (OP == 20) asm volatile("v_fma_f64 %0, %0, %1, 0.5" : "+v"(d[c]) : "v"(d[(c + 1) % CHAINS]));
+        if (OP == 21) asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(f[c]) : "v"(f[(c + 1) % CHAINS]), "v"(f[(c + 2) % CHAINS]), "v"(f[(c + 3) % CHAINS]));
+        if (OP == 22) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(f[c]) : "v"(f[(c + 1) % CHAINS]), "v"(f[(c + 2) % CHAINS]));
+        if (OP == 23) asm volatile("v_and_or_b32 %0, %1, %2, %3" : "=v"(i[c]) : "v"(i[(c + 1) % CHAINS]), "v"(i[(c + 2) % CHAINS]), "v"(i[(c + 3) % CHAINS]));
+        if (OP == 24) asm volatile("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(i[c]) : "v"(i[(c + 1) % CHAINS]), "v"(i[(c + 2) % CHAINS]));
+        if (OP == 25) asm volatile("v_med3_f32 %0, %1, %2, 2.0" : "=v"(f[c]) : "v"(f[(c + 1) % CHAINS]), "v"(f[(c + 2) % CHAINS]));
+        if (OP == 26) asm volatile("v_add_f32 %0, %0, %1" : "+v"(f[c]) : "v"(f[(c + 1) % CHAINS]));
+        if (OP == 27) asm volatile("v_cmp_lt_f32_e64 s[20:21], %0, %1" : : "v"(f[c]), "v"(f[(c + 1) % CHAINS]) : "s20", "s21");
+        if (OP == 28) asm volatile("v_cmp_lt_f32_e32 vcc, %0, %1" : : "v"(f[c]), "v"(f[(c + 1) % CHAINS]) : "vcc");
+        if (OP == 29) asm volatile("v_lshrrev_b32 %0, 15, %1" : "=v"(i[c]) : "v"(i[(c + 1) % CHAINS]));
+        if (OP == 30) asm volatile("v_pk_mov_b32 %0, %1, %2 op_sel:[1,1]" : "=v"(d[c]) : "v"(d[(c + 1) % CHAINS]), "v"(d[(c + 2) % CHAINS]));
+        if (OP == 31) asm volatile("v_and_or_b32 %0, %1, s20, 1.0" : "=v"(i[c]) : "v"(i[(c + 1) % CHAINS]) : "s20");
+        if (OP == 32) asm volatile("v_fmamk_f32 %0, %1, 0x33000000, %2" : "=v"(f[c]) : "v"(f[(c + 1) % CHAINS]), "v"(f[(c + 2) % CHAINS]));
+        if (OP == 33) asm volatile("v_med3_u32 %0, %1, s20, %2" : "=v"(i[c]) : "v"(i[(c + 1) % CHAINS]), "v"(i[(c + 2) % CHAINS]) : "s20");
+        if (OP == 34) asm volatile("v_min_u32 %0, %0, %1" : "+v"(i[c]) : "v"(i[(c + 1) % CHAINS]));
+        if (OP == 35) asm volatile("v_fma_f32 %0, %1, s20, %2" : "=v"(f[c]) : "v"(f[(c + 1) % CHAINS]), "v"(f[(c + 2) % CHAINS]) : "s20");
+        if (OP == 36) asm volatile("v_mul_f64 %0, s[20:21], %1" : "=v"(d[c]) : "v"(d[(c + 1) % CHAINS]) : "s20", "s21");
+        if (OP == 37) asm volatile("v_add_f32 %0, s20, %1" : "=v"(f[c]) : "v"(f[(c + 1) % CHAINS]) : "s20");
+        if (OP == 38) asm volatile("v_mul_f32 %0, s20, %1" : "=v"(f[c]) : "v"(f[(c + 1) % CHAINS]) : "s20");
+        if (OP == 39) asm volatile("v_max_f32 %0, %0, %1" : "+v"(f[c]) : "v"(f[(c + 1) % CHAINS]));
+        if (OP == 40) asm volatile("v_and_b32 %0, %0, %1" : "+v"(i[c]) : "v"(i[(c + 1) % CHAINS]));
+        if (OP == 41) asm volatile("v_and_b32 %0, 0x7fff, %1" : "=v"(i[c]) : "v"(i[(c + 1) % CHAINS]));
+        if (OP == 42) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(i[c]) : "v"(i[(c + 1) % CHAINS]));
+        if (OP == 43) asm volatile("v_add_u32 %0, s20, %1" : "=v"(i[c]) : "v"(i[(c + 1) % CHAINS]) : "s20");
+        if (OP == 44) asm volatile("v_cndmask_b32 %0, %1, %2, s[20:21]" : "=v"(i[c]) : "v"(i[(c + 1) % CHAINS]), "v"(i[(c + 2) % CHAINS]) : "s20", "s21");
+        if (OP == 45) asm volatile("v_max_u32 %0, %0, %1" : "+v"(i[c]) : "v"(i[(c + 1) % CHAINS]));
+        if (OP == 46) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(f[c]) : "v"(f[(c + 1) % CHAINS]));
+        if (OP == 47) asm volatile("v_fract_f32 %0, %1" : "=v"(f[c]) : "v"(f[(c + 1) % CHAINS]));
+        if (OP == 48) asm volatile("v_cvt_i32_f32 %0, %1" : "=v"(i[c]) : "v"(f[(c + 1) % CHAINS]));
+        if (OP == 49) asm volatile("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(i[c]) : "v"(i[(c + 1) % CHAINS]), "v"(i[(c + 2) % CHAINS]));
+        if (OP == 50) asm volatile("v_min_f32 %0, %0, %1" : "+v"(f[c]) : "v"(f[(c + 1) % CHAINS]));
+        if (OP == 51) asm volatile("v_or_b32 %0, 1.0, %1" : "=v"(i[c]) : "v"(i[(c + 1) % CHAINS]));
+        if (OP == 52) asm volatile("v_add_f64 %0, %1, 0.5" : "=v"(d[c]) : "v"(d[(c + 1) % CHAINS]));
     }
 }
 
@@ -123,6 +155,38 @@ int main()
     int* drnd; hipMalloc(&drnd, 4096 * 4);
     std::vector<int> r(4096); srand(1); for (auto& x : r) x = rand();
     hipMemcpy(drnd, r.data(), 4096 * 4, hipMemcpyHostToDevice);
+    run<26>("v_add_f32", dout, ncu);
+    run<34>("v_min_u32", dout, ncu);
+    run<29>("v_lshrrev_b32", dout, ncu);
+    run<21>("v_fma_f32 3src", dout, ncu);
+    run<35>("v_fma_f32 v,s,v", dout, ncu);
+    run<22>("v_fmac_f32", dout, ncu);
+    run<32>("v_fmamk_f32", dout, ncu);
+    run<23>("v_and_or 3src", dout, ncu);
+    run<31>("v_and_or v,s,c", dout, ncu);
+    run<24>("v_lshl_add_u32", dout, ncu);
+    run<25>("v_med3_f32", dout, ncu);
+    run<33>("v_med3_u32", dout, ncu);
+    run<27>("v_cmp_f32 e64", dout, ncu);
+    run<28>("v_cmp_f32 e32", dout, ncu);
+    run<30>("v_pk_mov_b32", dout, ncu);
+    run<36>("v_mul_f64 s,v", dout, ncu);
+    run<37>("v_add_f32 s,v", dout, ncu);
+    run<38>("v_mul_f32 s,v", dout, ncu);
+    run<43>("v_add_u32 s,v", dout, ncu);
+    run<39>("v_max_f32", dout, ncu);
+    run<50>("v_min_f32", dout, ncu);
+    run<45>("v_max_u32", dout, ncu);
+    run<40>("v_and_b32", dout, ncu);
+    run<41>("v_and_b32 lit", dout, ncu);
+    run<51>("v_or_b32 1.0", dout, ncu);
+    run<42>("v_sub_u32", dout, ncu);
+    run<46>("v_sub_f32", dout, ncu);
+    run<44>("v_cndmask sgpr", dout, ncu);
+    run<47>("v_fract_f32", dout, ncu);
+    run<48>("v_cvt_i32_f32", dout, ncu);
+    run<49>("v_lshl_or_b32", dout, ncu);
+    run<52>("v_add_f64 0.5", dout, ncu);
     run<0>("v_fma_f32", dout, ncu);
     run<14>("v_mul_f32", dout, ncu);
     run<15>("v_pk_fma_f32", dout, ncu);

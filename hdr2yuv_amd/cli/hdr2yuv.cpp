@@ -181,9 +181,6 @@ int main(int argc, char **argv)
     if (rc) { printf("ERROR: %s\n", h2y_last_error(nullptr)); return 1; }
 
     const size_t n = (size_t)d.width * d.height, pb = h2y_plane_bytes(&d), ob = h2y_frame_bytes(&d);
-    std::vector<char> planes[3];
-    for (auto &p : planes) p.resize(pb);
-    std::vector<uint16_t> out(ob / 2);
     FILE *fin = nullptr;
     if (a.synthetic < 0) {
         fin = fopen(a.src, "rb");
@@ -193,13 +190,30 @@ int main(int argc, char **argv)
     FILE *fout = fopen(a.dst, "ab"); /* tiff.cpp:440: ios::ate | ios::app */
     if (!fout) { printf("ERROR: unable to open %s\n", a.dst); return 1; }
 
+    /* The reader fills the pinned slot of the pipeline directly, the writer appends what comes out of
+     * it two frames later: upload, conversion and download of neighbouring frames overlap. */
+    const int depth = 3;
+    rc = h2y_stream_open(ctx, &d, depth);
+    if (rc) { printf("ERROR: %s\n", h2y_last_error(ctx)); return 1; }
+    int in_flight = 0, written = 0;
+    auto drain_one = [&]() -> int {
+        const uint16_t *yuv = nullptr;
+        if (h2y_stream_output(ctx, &yuv)) { printf("ERROR: %s\n", h2y_last_error(ctx)); return 1; }
+        if (fwrite(yuv, 1, ob, fout) != ob) { printf("ERROR: short write to %s\n", a.dst); return 1; }
+        if (a.verbose > 0) printf("frame %d: %zu bytes appended to %s\n", written, ob, a.dst);
+        written++;
+        in_flight--;
+        return 0;
+    };
     for (int f = 0; f < (a.n_frames > 0 ? a.n_frames : 1); f++) {
+        void *planes[3];
+        if (h2y_stream_input(ctx, planes)) { printf("ERROR: %s\n", h2y_last_error(ctx)); return 1; }
         if (fin) {
             /* file plane order -> memory planes (0=G/Y, 1=B/Cb, 2=R/Cr) */
             const int order_rgb[3] = {2, 0, 1}, order_nat[3] = {0, 1, 2};
             const int *ord = rgb_order ? order_rgb : order_nat;
             size_t got = 0;
-            for (int k = 0; k < 3; k++) got += fread(planes[ord[k]].data(), 1, pb, fin);
+            for (int k = 0; k < 3; k++) got += fread(planes[ord[k]], 1, pb, fin);
             if (got != 3 * pb) {
                 if (f == 0) { printf("ERROR: only %zu bytes read from %s, expecting %zu\n", got, a.src, 3 * pb); return 1; }
                 break;
@@ -212,17 +226,18 @@ int main(int argc, char **argv)
                     float v = (float)(s >> 8) * (1.0f / 16777216.0f);
                     if (i == 0) v = 0.0f;
                     if (i == 1) v = 1.0f;
-                    if (d.in_sample_type == H2Y_SAMPLE_F16) ((uint16_t *)planes[c].data())[i] = f32_to_f16(v);
-                    else ((float *)planes[c].data())[i] = v;
+                    if (d.in_sample_type == H2Y_SAMPLE_F16) ((uint16_t *)planes[c])[i] = f32_to_f16(v);
+                    else ((float *)planes[c])[i] = v;
                 }
             }
         }
-        const void *in3[3] = {planes[0].data(), planes[1].data(), planes[2].data()};
-        rc = h2y_convert_frame(ctx, &d, in3, out.data());
-        if (rc) { printf("ERROR: %s\n", h2y_last_error(ctx)); return 1; }
-        if (fwrite(out.data(), 1, ob, fout) != ob) { printf("ERROR: short write to %s\n", a.dst); return 1; }
-        if (a.verbose > 0) printf("frame %d: %zu bytes appended to %s\n", f, ob, a.dst);
+        if (h2y_stream_submit(ctx)) { printf("ERROR: %s\n", h2y_last_error(ctx)); return 1; }
+        in_flight++;
+        if (in_flight == depth - 1 && drain_one()) return 1;
     }
+    while (in_flight > 0)
+        if (drain_one()) return 1;
+    h2y_stream_close(ctx);
     if (fin) fclose(fin);
     fclose(fout);
     h2y_ctx_destroy(ctx);

@@ -618,6 +618,7 @@ int h2y_ctx_set_stream(h2y_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
     if (ctx->pending) return fail(ctx, H2Y_EINVAL, "a batch is pending: call h2y_batch_finish first");
+    if (ctx->streaming) return fail(ctx, H2Y_EINVAL, "a stream is open: close it first");
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return H2Y_OK;
 }
@@ -626,6 +627,7 @@ int h2y_convert_batch_enqueue(h2y_ctx *ctx, const h2y_desc *d, int n_frames, con
 {
     if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
     if (ctx->pending) return fail(ctx, H2Y_EINVAL, "a batch is already pending: call h2y_batch_finish first");
+    if (ctx->streaming) return fail(ctx, H2Y_EINVAL, "a stream is open: close it first");
     const char *why;
     int rc = h2y_desc_check(d, &why);
     if (rc) return fail(ctx, rc, "descriptor: %s", why);
@@ -740,6 +742,7 @@ int h2y_convert_frame(h2y_ctx *ctx, const h2y_desc *d, const void *const in_plan
 {
     if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
     if (ctx->pending) return fail(ctx, H2Y_EINVAL, "a batch is pending: call h2y_batch_finish first");
+    if (ctx->streaming) return fail(ctx, H2Y_EINVAL, "a stream is open: close it first");
     const char *why;
     int rc = h2y_desc_check(d, &why);
     if (rc) return fail(ctx, rc, "descriptor: %s", why);
@@ -983,6 +986,7 @@ int h2y_pic_stats(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3], fl
 {
     if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
     if (ctx->pending) return fail(ctx, H2Y_EINVAL, "a batch is pending");
+    if (ctx->streaming) return fail(ctx, H2Y_EINVAL, "a stream is open: close it first");
     const char *why;
     int rc = h2y_desc_check(d, &why);
     if (rc) return fail(ctx, rc, "descriptor: %s", why);
@@ -1004,6 +1008,7 @@ int h2y_matrix_convert(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3
 {
     if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
     if (ctx->pending) return fail(ctx, H2Y_EINVAL, "a batch is pending");
+    if (ctx->streaming) return fail(ctx, H2Y_EINVAL, "a stream is open: close it first");
     const char *why;
     int rc = h2y_desc_check(d, &why);
     if (rc) return fail(ctx, rc, "descriptor: %s", why);
@@ -1064,6 +1069,7 @@ int h2y_subsample_420(h2y_ctx *ctx, int width, int height, int bit_depth, int ch
 {
     if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
     if (ctx->pending) return fail(ctx, H2Y_EINVAL, "a batch is pending");
+    if (ctx->streaming) return fail(ctx, H2Y_EINVAL, "a stream is open: close it first");
     if (width < 2 || height < 2 || (width & 1) || (height & 1) || bit_depth < 8 || bit_depth > 16 || !d_src || !d_dst)
         return fail(ctx, H2Y_EINVAL, "bad subsample arguments");
     if (chroma_resampler_type == 0 && ((width & 3) || (height & 3))) return fail(ctx, H2Y_EINVAL, "box needs multiples of 4");

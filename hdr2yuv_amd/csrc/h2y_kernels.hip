@@ -1181,10 +1181,25 @@ __global__ __launch_bounds__(256) void k_fir420(fir_args a)
      *    (the reference's clamped indices, convert.cpp:295-300 and :337-347) */
     const bool interior = xs >= 0 && xs + FIR_LCOLS <= W && (W & 7) == 0 && ((uintptr_t)src & 15) == 0;
     if (interior) {
-        for (int i = threadIdx.x; i < FIR_ROWS * (FIR_LCOLS / 8); i += 256) {
+        /* all of a thread's loads are issued before the first is stored to LDS (one exposed memory
+         * latency per block instead of one per round) */
+        constexpr int N16 = FIR_ROWS * (FIR_LCOLS / 8), ROUNDS = (N16 + 255) / 256;
+        typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+        u32x4v q[ROUNDS];
+#pragma unroll
+        for (int k = 0; k < ROUNDS; k++) {
+            const int i = min((int)threadIdx.x + 256 * k, N16 - 1);
             const int r = i / (FIR_LCOLS / 8), c8 = i - r * (FIR_LCOLS / 8);
             const int y = min(max(ys + r, 0), H - 1);
-            *reinterpret_cast<uint4 *>(&s444[r][c8 * 8]) = *reinterpret_cast<const uint4 *>(src + (size_t)y * W + xs + c8 * 8);
+            q[k] = gload<u32x4v>(src, (size_t)(((size_t)y * W + xs + c8 * 8) >> 3));
+        }
+#pragma unroll
+        for (int k = 0; k < ROUNDS; k++) {
+            const int i = (int)threadIdx.x + 256 * k;
+            if (i < N16) {
+                const int r = i / (FIR_LCOLS / 8), c8 = i - r * (FIR_LCOLS / 8);
+                *reinterpret_cast<u32x4v *>(&s444[r][c8 * 8]) = q[k];
+            }
         }
     } else {
         for (int i = threadIdx.x; i < FIR_ROWS * FIR_LCOLS; i += 256) {

@@ -545,3 +545,70 @@ def test_full_size_batch_of_frames(ctx, oracle, name):
         got = dev_out[f].cpu().numpy().view(np.uint16)
         want = oracle.convert_frame(od, host[f])
         assert np.array_equal(got, want), f"{name} frame {f}: {np.count_nonzero(got != want)} samples differ"
+
+
+def test_fuzz_descriptors_against_oracle(ctx, oracle):
+    """Seeded sweep over the descriptor space: sizes (all tile / chunk remainders, odd heights, narrow
+    widths), sample types, bit depths, matrices, ranges, resamplers, statistics (measured, overridden,
+    non-trivial), single frames and small batches -- every kernel variant the dispatcher can pick."""
+    import torch
+
+    rng = np.random.default_rng(20261004)
+    mats = [h.MATRIX_BT2020NC, h.MATRIX_BT709, h.MATRIX_YDZDX, h.MATRIX_Y100, h.MATRIX_Y500, h.MATRIX_GBR]
+    n_cases = 0
+    for it in range(300):
+        chroma = h.CHROMA_420 if rng.random() < 0.6 else h.CHROMA_444
+        res = int(rng.integers(0, 2))
+        if chroma == h.CHROMA_420:
+            step = 4 if res == 0 else 2
+            w = int(rng.integers(1, 90)) * step
+            hh = int(rng.integers(1, 40)) * step
+        else:
+            w = int(rng.integers(1, 300))
+            hh = int(rng.integers(1, 70))
+        sample = [h.SAMPLE_F32, h.SAMPLE_F32, h.SAMPLE_F16, h.SAMPLE_U16][int(rng.integers(0, 4))]
+        depth = int(rng.choice([8, 10, 12, 14, 16]))
+        mat = mats[int(rng.integers(0, len(mats)))]
+        full = int(rng.integers(0, 2))
+        kw = dict(dst_depth=depth, dst_matrix=mat, chroma=chroma, resampler=res, full_range=full, sample=sample)
+        same_transfer = rng.random() < 0.2
+        if same_transfer:
+            kw.update(src_transfer=h.TRANSFER_PQ, dst_transfer=h.TRANSFER_PQ)
+        if sample == h.SAMPLE_U16:
+            kw["src_depth"] = int(rng.choice([d for d in (10, 12, 16) if d >= depth] or [16]))
+            if kw["src_depth"] < depth:
+                kw["dst_depth"] = kw["src_depth"]
+        mode = int(rng.integers(0, 4))  # 0: measured stats 0/1, 1: override 0/1, 2: measured with ceiling 2, 3: override (-1, 2)
+        if mode == 1:
+            kw["stats"] = [(0, 1)] * 3
+        if mode == 3:
+            kw["stats"] = [(-1, 2)] * 3
+        d = h.make_desc(w, hh, **kw)
+        n = w * hh
+        nframes = 1 if rng.random() < 0.7 else int(rng.integers(2, 5))
+        frames = []
+        for _ in range(nframes):
+            if sample == h.SAMPLE_U16:
+                planes = [rng.integers(0, 1 << kw["src_depth"], n).astype(np.uint16) for _ in range(3)]
+            else:
+                planes = _rand_planes(rng, w, hh, sample, plant=(n >= 2))
+                if mode == 2 and n >= 3 and sample == h.SAMPLE_F32:
+                    planes[int(rng.integers(0, 3))][2] = np.float32(2.25)
+                if n >= 16 and rng.random() < 0.3 and sample == h.SAMPLE_F32:
+                    planes[1][5:9] = 0.0
+                    planes[2][9] = np.float32(-0.5)
+            frames.append(planes)
+        od = _to_oracle_desc(d)
+        if nframes == 1:
+            got = [ctx.convert_frame(d, frames[0])]
+        else:
+            conv = (lambda p: torch.from_numpy(p.view(np.int16) if p.dtype == np.uint16 else p).cuda())
+            dev_in = [[conv(np.ascontiguousarray(p)) for p in fr] for fr in frames]
+            dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda") for _ in frames]
+            ctx.convert_batch(d, dev_in, dev_out)
+            got = [t.cpu().numpy().view(np.uint16) for t in dev_out]
+        for f, planes in enumerate(frames):
+            want = oracle.convert_frame(od, planes)
+            assert np.array_equal(got[f], want), (it, f, w, hh, kw, mode, int(np.count_nonzero(got[f] != want)))
+        n_cases += 1
+    assert n_cases == 300

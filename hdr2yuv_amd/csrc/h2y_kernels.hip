@@ -2,14 +2,19 @@
  * h2y_kernels.hip -- gfx950 kernels of the convert path.
  *
  *   k_stats        pic_stats()            common.cpp:66-139   (pre-pass form)
- *   k_fused        matrix_convert()       convert.cpp:879-1221
+ *   the fused kernels: matrix_convert()   convert.cpp:879-1221
  *                  + convert() box / 4:4:4 convert.cpp:802-859 (+ :91-172)
  *                  + write_yuv() clamp     tiff.cpp:457-550
  *                  + pic_stats() min/max of the same samples, as a by-product
+ *     k_fused_t1     LINEAR -> PQ, float input, <= 12 bits: binary32 first tier, the rest redone in place
+ *     k_fused2       the binary64 tier for every sample (16 bits, u16 input), or no PQ at all (equal transfers)
+ *     k_fused_lut16  half-float input: PQ of all 16 384 halves in LDS
+ *     k_fused        generic form (runtime matrix / transfer flags, odd heights), k_fused_narrow (width % 4 != 0)
  *   k_fir420       Subsample444to420_FIR  convert.cpp:261-383 + write_yuv clamp
  *   k_box420       Subsample444to420_box  convert.cpp:91-172 (stage entry only)
+ *   k_inverse      matrix_inverse()       convert.cpp:1320-1867
  *   k_stats_final  (int) floor/ceiling    common.cpp:135-136, and the check of
- *                  the values k_fused assumed against the ones it measured
+ *                  the values the fused kernel assumed against the ones it measured
  *
  * The path is HBM-bound elementwise work: no MFMA.  Layout in HBM is the
  * reference's: three planar row-major planes in (G,B,R) order, stride = width;

@@ -53,6 +53,8 @@ clip_limits make_clip(int bit_depth, int full_range)
 }
 
 const int kMaxEvents = 64;
+const double kT1DenseShare = 0.08; /* T1 costs ~1.6x more per redone tile, k_fused2 ~1.12x overall: break-even near 8 % */
+const int kT1SkipBatches = 8;
 const int kFirSubBatch = 32; /* frames per fused launch on the FIR path: every launch pays its table staging and its last redo pass */
 
 } // namespace
@@ -72,6 +74,15 @@ struct h2y_ctx {
     frame_io *d_frames = nullptr, *h_frames = nullptr;
     size_t frames_cap = 0;
     float *d_partial = nullptr;
+    uint32_t *d_redo = nullptr; /* k_fused_t1: per-wave counts of redone tiles */
+    size_t redo_cap = 0;
+    /* The first tier is slow on pictures with many exactly-zero samples (black bars: every such tile is done twice).
+     * The kernel counts the tiles it had to redo; when their share in a batch exceeds kT1DenseShare the next
+     * kT1SkipBatches batches go to k_fused2 (the binary64 tier answers zero by itself), then the first tier is
+     * tried again. */
+    int t1_skip = 0, t1_skip_len = 0;
+    bool cur_skip_t1 = false;
+    bool last_was_t1 = false;
     size_t partial_cap = 0;
     frame_stats *d_fstats = nullptr, *h_fstats = nullptr;
     size_t fstats_cap = 0;
@@ -262,6 +273,26 @@ int grid_for(const h2y_ctx *ctx, const fused_variant &v, uint64_t total_chunks)
     return (int)g;
 }
 
+/* start of a batch: is the first tier to be skipped this time? */
+void t1_begin_batch(h2y_ctx *ctx)
+{
+    ctx->cur_skip_t1 = ctx->t1_skip > 0;
+    if (ctx->cur_skip_t1) ctx->t1_skip--;
+}
+/* end of a batch that ran k_fused_t1: how many of its tiles had to be redone */
+void t1_end_batch(h2y_ctx *ctx, const h2y_desc *d, const frame_stats *fs, int n)
+{
+    if (!ctx->last_was_t1 || n < 1) return;
+    uint64_t redone = 0;
+    for (int f = 0; f < n; f++) redone += fs[f].redone;
+    const uint64_t tiles = (uint64_t)n * make_geom(d, 1024).tiles;
+    if ((double)redone > kT1DenseShare * (double)tiles) {
+        /* still dense at the next probe: stay away twice as long (8, 16, ... 128 batches) */
+        ctx->t1_skip_len = ctx->t1_skip_len ? (ctx->t1_skip_len < 128 ? 2 * ctx->t1_skip_len : 128) : kT1SkipBatches;
+        ctx->t1_skip = ctx->t1_skip_len;
+    } else ctx->t1_skip_len = 0;
+}
+
 /* known: the floor/ceiling the kernels will assume, when the HOST knows them (hint or
  * override); NULL when they only exist in device memory (stats pre-pass). */
 /* H2Y_T1=0 in the environment keeps the binary32 first tier off (A/B timing) */
@@ -317,6 +348,8 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
     fused_variant var = pick_variant(d, pp, out_kind, known, &sn);
     /* k_fused_t1's redo list numbers tiles as frame * tiles + tile in 32 bits */
     if ((var.pipe == 4 || var.pipe == 5) && (uint64_t)n * make_geom(d, h2y_fused_threads(var)).tiles >= 0xFFFFFFFFull) var.pipe -= 3;
+    if ((var.pipe == 4 || var.pipe == 5) && ctx->cur_skip_t1) var.pipe -= 3; /* dense zeros lately: binary64 tier for now */
+    ctx->last_was_t1 = var.pipe == 4 || var.pipe == 5;
     const geom g = make_geom(d, h2y_fused_threads(var));
     const size_t npix = (size_t)d->width * d->height;
     const int step = out_kind == H2Y_OUT_444TMP ? kFirSubBatch : n;
@@ -346,7 +379,13 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         const int waves = h2y_fused_threads(var) / 64; /* the fused kernels leave one min/max record per wave */
         int rc = ensure(ctx, ctx->d_partial, ctx->partial_cap, (size_t)nf * grid * waves * 6 * sizeof(float));
         if (rc) return rc;
+        const bool t1 = var.pipe == 4 || var.pipe == 5;
+        if (t1) {
+            rc = ensure(ctx, ctx->d_redo, ctx->redo_cap, (size_t)nf * grid * waves * sizeof(uint32_t));
+            if (rc) return rc;
+        }
         fused_args a;
+        a.redo_count = t1 ? ctx->d_redo : nullptr;
         a.frames = ctx->d_frames + ctx->slot_base + f0;
         a.n_frames = nf;
         a.width = d->width;
@@ -376,6 +415,7 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         final_args fa;
         fa.partial = ctx->d_partial;
         fa.nblk = grid * waves;
+        fa.redo_count = t1 ? ctx->d_redo : nullptr;
         fa.out = ctx->d_fstats + fstats_offset + f0;
         fa.is_u16 = d->in_sample_type == H2Y_SAMPLE_U16;
         fa.src_bit_depth = d->src_bit_depth;
@@ -453,6 +493,7 @@ int run_stats(h2y_ctx *ctx, const h2y_desc *d, const void *const in[3], int slot
     fa.out = ctx->d_fstats + slot;
     fa.is_u16 = d->in_sample_type == H2Y_SAMPLE_U16;
     fa.src_bit_depth = d->src_bit_depth;
+    fa.redo_count = nullptr;
     fa.check = 0;
     fa.assumed = nullptr;
     fa.publish = publish;
@@ -595,6 +636,7 @@ void h2y_ctx_destroy(h2y_ctx *ctx)
     (void)hipFree(ctx->d_frames);
     (void)hipHostFree(ctx->h_frames);
     (void)hipFree(ctx->d_partial);
+    (void)hipFree(ctx->d_redo);
     (void)hipFree(ctx->d_fstats);
     (void)hipHostFree(ctx->h_fstats);
     (void)hipFree(ctx->d_assumed);
@@ -673,6 +715,7 @@ int h2y_convert_batch_enqueue(h2y_ctx *ctx, const h2y_desc *d, int n_frames, con
         check = true;
         host_knows = false; /* the values exist only in device memory */
     }
+    t1_begin_batch(ctx);
     rc = run_frames(ctx, d, ctx->p_frames.data(), n_frames, ctx->d_assumed, host_knows ? ctx->h_assumed : nullptr, check, 0, true);
     if (rc) return rc;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->h_fstats, ctx->d_fstats, n_frames * sizeof(frame_stats), hipMemcpyDeviceToHost, ctx->stream));
@@ -701,6 +744,7 @@ int h2y_batch_finish(h2y_ctx *ctx, int *n_redone)
     ctx->last_launches = ctx->n_ev;
     int redone = 0;
     const h2y_desc *d = &ctx->p_desc;
+    t1_end_batch(ctx, d, ctx->h_fstats, ctx->p_n);
     if (ctx->p_check) {
         for (int f = 0; f < ctx->p_n; f++) {
             if (!ctx->h_fstats[f].mismatch) continue;
@@ -776,10 +820,13 @@ int h2y_convert_frame(h2y_ctx *ctx, const h2y_desc *d, const void *const in_plan
         HIP_TRY(ctx, hipMemcpyAsync(ctx->d_assumed, as, sizeof *as, hipMemcpyHostToDevice, ctx->stream));
     }
     ctx->n_ev = 0;
+    t1_begin_batch(ctx);
     rc = run_frames(ctx, d, &io, 1, ctx->d_assumed, host_knows ? ctx->h_assumed : nullptr, false, 0, true);
     if (rc) return rc;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_fstats, ctx->d_fstats, sizeof(frame_stats), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(out_yuv, ctx->d_out, ob, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    t1_end_batch(ctx, d, ctx->h_fstats, 1);
     float ms = 0.f;
     for (int i = 0; i < ctx->n_ev; i++) {
         float t = 0.f;
@@ -938,6 +985,7 @@ int h2y_stream_submit(h2y_ctx *ctx)
     }
     ctx->slot_base = slot;
     ctx->n_ev = 0;
+    ctx->cur_skip_t1 = false; /* PCIe-bound here: no steering between the tiers */
     rc = run_frames(ctx, d, &io, 1, ctx->d_assumed, nullptr, false, slot, false);
     ctx->slot_base = 0;
     if (rc) return rc;
@@ -1056,6 +1104,7 @@ int h2y_matrix_convert(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3
     a.table1 = ctx->d_table1;
     memset(&a.sn, 0, sizeof a.sn);
     a.tiles_magic = 0;
+    a.redo_count = nullptr;
     a.partial = ctx->d_partial;
     a.assumed = ctx->d_assumed;
     a.pp = pp;

@@ -34,7 +34,7 @@ struct frame_stats {
     int32_t floor_[3]; /* pic_stats estimated_floor   */
     int32_t ceil_[3];  /* pic_stats estimated_ceiling */
     int32_t mismatch;  /* assumed != measured         */
-    int32_t pad;
+    uint32_t redone;   /* k_fused_t1: tiles of this frame the first tier could not settle (redone by the exact tiers) */
 };
 
 /* estimated_floor/ceiling the pixel kernels normalise with (convert.cpp:939-940).
@@ -59,6 +59,7 @@ struct fused_args {
     h2y::t1_sens sn;          /* k_fused_t1: sensitivity windows */
     uint32_t tiles_magic;     /* floor(2^32 / tiles_per_frame): k_fused_t1's redo list holds frame * tiles + tile */
     float *partial;           /* [n_frames][grid][6] */
+    uint32_t *redo_count;     /* k_fused_t1: [n_frames][grid * waves] tiles sent to the redo list, or NULL */
     const assumed_stats *assumed;
     h2y::pix_params pp;       /* offset/range/norm_identity are filled in-kernel from *assumed */
 };
@@ -83,6 +84,7 @@ struct stats_args {
 
 struct final_args {
     const float *partial; /* [n_frames][nblk][6] */
+    const uint32_t *redo_count; /* [n_frames][nblk] or NULL */
     int nblk;
     frame_stats *out; /* [n_frames] */
     int is_u16, src_bit_depth;

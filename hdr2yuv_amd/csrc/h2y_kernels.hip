@@ -768,6 +768,7 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
         const uint32_t gbase = (uint32_t)(((uint64_t)f * a.chunks_per_frame) % G);
         const uint32_t k_next_frame = (uint32_t)((blockIdx.x + G - (uint32_t)(((uint64_t)(f + 1) * a.chunks_per_frame) % G)) % G);
         const uint32_t id_base = (uint32_t)f * a.tiles_per_frame;
+        uint32_t flagged_f = 0; /* tiles of this frame this wave sent to the list (the host steers by their share) */
         uint32_t k = (blockIdx.x + G - gbase) % G;
         while (k < a.chunks_per_frame) {
             if (!have) { /* nothing on its way (first tile of the launch, or a block that skipped frames) */
@@ -839,6 +840,7 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
                     /* unflagged lanes write to the spare last slot: no branch in the loop body */
                     my_list[flagged ? n_redo + below : (uint32_t)(H2Y_REDO_CAP - 1)] = id_base + umin32(tt, a.tiles_per_frame - 1u);
                     n_redo += (uint32_t)__popcll(m);
+                    flagged_f += (uint32_t)__popcll(m);
                 }
             }
             if (n_redo >= WAVE) { /* 64 tiles to redo: one per lane */
@@ -848,6 +850,7 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
             }
         }
         wave_store_mm(mm, a.partial + (((size_t)f * G + blockIdx.x) * (H2Y_T1_THREADS / WAVE) + threadIdx.x / WAVE) * 6);
+        if (a.redo_count && lane == 0) a.redo_count[((size_t)f * G + blockIdx.x) * (H2Y_T1_THREADS / WAVE) + wave] = flagged_f;
     }
     if (n_redo) redo_pass<IN_KIND, OUT_KIND, MODE, PIPE>(&s_rc, &s_pp, s_t2, my_list, 0u, n_redo);
     (void)lane;
@@ -1096,6 +1099,16 @@ __global__ __launch_bounds__(256) void k_stats_final(final_args a)
             mm.hi[c] = fmaxf(mm.hi[c], p[i * 6 + 2 * c + 1]);
         }
     frame_stats *out = a.out + f;
+    if (a.redo_count) { /* total of the per-wave counts: a handful of atomics in LDS-free form would do; this is one block per frame */
+        __shared__ uint32_t s_cnt;
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        uint32_t c = 0;
+        for (int i = threadIdx.x; i < a.nblk; i += blockDim.x) c += a.redo_count[(size_t)f * a.nblk + i];
+        atomicAdd(&s_cnt, c);
+        __syncthreads();
+        if (threadIdx.x == 0) out->redone = s_cnt;
+    } else if (threadIdx.x == 0) out->redone = 0;
     block_store_mm<4>(mm, s_red, out->mm);
     if (threadIdx.x == 0) {
         int bad = 0;

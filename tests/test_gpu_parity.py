@@ -612,3 +612,35 @@ def test_fuzz_descriptors_against_oracle(ctx, oracle):
             assert np.array_equal(got[f], want), (it, f, w, hh, kw, mode, int(np.count_nonzero(got[f] != want)))
         n_cases += 1
     assert n_cases == 300
+
+
+def test_tier_steering_on_black_frames(oracle):
+    """Frames full of exact zeros make the first-tier kernel redo every tile; the context notices (share
+    of redone tiles) and sends the next batches to the binary64-tier kernel, probing the first tier again
+    later.  Bytes are the oracle's whichever kernel runs."""
+    import torch
+
+    w, hh = 512, 256
+    d = h.make_desc(w, hh, dst_depth=12, dst_matrix=h.MATRIX_BT2020NC, resampler=0, stats=[(0, 1)] * 3)
+    od = _to_oracle_desc(d)
+    rng = np.random.default_rng(5)
+    black = [np.zeros(w * hh, np.float32) for _ in range(3)]
+    noise = [rng.uniform(0, 1, w * hh).astype(np.float32) for _ in range(3)]
+    want_black, want_noise = oracle.convert_frame(od, black), oracle.convert_frame(od, noise)
+    c = h.Context(0)
+    try:
+        names = []
+        for step in range(14):
+            planes = black if step < 11 else noise
+            dev_in = [[torch.from_numpy(p).cuda() for p in planes] for _ in range(2)]
+            dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda") for _ in range(2)]
+            c.convert_batch(d, dev_in, dev_out)
+            names.append(c.last_kernel_name())
+            for t in dev_out:
+                assert np.array_equal(t.cpu().numpy().view(np.uint16), want_black if step < 11 else want_noise), step
+        assert names[0] == "k_fused_t1"              # first batch: nothing known yet
+        assert names[1:9] == ["k_fused2"] * 8        # eight batches away from the first tier
+        assert names[9] == "k_fused_t1"              # probe: still black
+        assert names[10] == "k_fused2"               # away again (for 16 batches now)
+    finally:
+        c.close()

@@ -57,6 +57,21 @@ def main():
         const = [[torch.full((w * hh,), 0.3 + 0.1 * c, dtype=torch.float32, device="cuda") for c in range(3)] for _ in range(F)]
         timeit(ctx, h.make_desc(w, hh, dst_depth=12, dst_matrix=9, resampler=0, stats=[(0, 1)] * 3), const,
                "C2 box constant input (LDS broadcast)")
+    if on("bars"):
+        # letterboxed 2.39:1 in 16:9: 12.8 % black rows at the top and at the bottom; and an all-black frame
+        bar = int(hh * 0.128) // 2 * 2
+        lb = []
+        for k in range(F):
+            fr = [p.clone() for p in synth[k]]
+            for p in fr:
+                p[: bar * w] = 0.0
+                p[-bar * w:] = 0.0
+                p[bar * w] = 0.0
+                p[bar * w + 1] = 1.0
+            lb.append(fr)
+        timeit(ctx, h.make_desc(w, hh, dst_depth=12, dst_matrix=9, resampler=0), lb, "C2 box, letterboxed (25.6 % black rows)")
+        blk = [[torch.zeros(w * hh, dtype=torch.float32, device="cuda") for _ in range(3)] for _ in range(F)]
+        timeit(ctx, h.make_desc(w, hh, dst_depth=12, dst_matrix=9, resampler=0, stats=[(0, 1)] * 3), blk, "C2 box, all-black frames")
     if on("smooth"):
         # smooth ramp: neighbouring pixels share table segments, like natural images
         ramp = (torch.arange(w * hh, device="cuda", dtype=torch.float32) % w) / w

@@ -75,6 +75,9 @@ struct h2y_ctx {
     size_t frames_cap = 0;
     float *d_partial = nullptr;
     uint32_t *d_redo = nullptr; /* k_fused_t1: per-wave counts of redone tiles */
+    uint32_t *d_low = nullptr;  /* k_fused_t1: per-frame flag "a sample <= -1 was seen" (zero between launches) */
+    size_t low_cap = 0;
+    bool approx_min = false;    /* the last batch's statistics hold a subsampled minimum (exact only where they match) */
     size_t redo_cap = 0;
     /* The first tier is slow on pictures with many exactly-zero samples (black bars: every such tile is done twice).
      * The kernel counts the tiles it had to redo; when their share in a batch exceeds kT1DenseShare the next
@@ -384,8 +387,19 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
             rc = ensure(ctx, ctx->d_redo, ctx->redo_cap, (size_t)nf * grid * waves * sizeof(uint32_t));
             if (rc) return rc;
         }
+        const bool approx = var.pipe == 4; /* first tier, assumed floor 0 / ceiling 1: subsampled minimum */
+        if (approx) {
+            const size_t need = (size_t)(nf > 64 ? nf : 64) * sizeof(uint32_t);
+            if (ctx->low_cap < need) {
+                rc = ensure(ctx, ctx->d_low, ctx->low_cap, need);
+                if (rc) return rc;
+                HIP_TRY(ctx, hipMemsetAsync(ctx->d_low, 0, need, ctx->stream)); /* the kernels keep it zero from here on */
+            }
+        }
+        if (check) ctx->approx_min = approx;
         fused_args a;
         a.redo_count = t1 ? ctx->d_redo : nullptr;
+        a.low_flag = approx ? ctx->d_low : nullptr;
         a.frames = ctx->d_frames + ctx->slot_base + f0;
         a.n_frames = nf;
         a.width = d->width;
@@ -416,6 +430,7 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         fa.partial = ctx->d_partial;
         fa.nblk = grid * waves;
         fa.redo_count = t1 ? ctx->d_redo : nullptr;
+        fa.low_flag = approx ? ctx->d_low : nullptr;
         fa.out = ctx->d_fstats + fstats_offset + f0;
         fa.is_u16 = d->in_sample_type == H2Y_SAMPLE_U16;
         fa.src_bit_depth = d->src_bit_depth;
@@ -494,6 +509,7 @@ int run_stats(h2y_ctx *ctx, const h2y_desc *d, const void *const in[3], int slot
     fa.is_u16 = d->in_sample_type == H2Y_SAMPLE_U16;
     fa.src_bit_depth = d->src_bit_depth;
     fa.redo_count = nullptr;
+    fa.low_flag = nullptr;
     fa.check = 0;
     fa.assumed = nullptr;
     fa.publish = publish;
@@ -637,6 +653,7 @@ void h2y_ctx_destroy(h2y_ctx *ctx)
     (void)hipHostFree(ctx->h_frames);
     (void)hipFree(ctx->d_partial);
     (void)hipFree(ctx->d_redo);
+    (void)hipFree(ctx->d_low);
     (void)hipFree(ctx->d_fstats);
     (void)hipHostFree(ctx->h_fstats);
     (void)hipFree(ctx->d_assumed);
@@ -748,6 +765,20 @@ int h2y_batch_finish(h2y_ctx *ctx, int *n_redone)
     if (ctx->p_check) {
         for (int f = 0; f < ctx->p_n; f++) {
             if (!ctx->h_fstats[f].mismatch) continue;
+            if (ctx->approx_min) {
+                /* the kernel kept only a subsample of the minimum: what it measured is exact where it matched the
+                 * assumption, not here -- take pic_stats() of this frame first, then the pixels, as
+                 * h2y_convert_frame() does */
+                int rc = run_stats(ctx, d, ctx->p_frames[f].in, (int)ctx->frames_cap, ctx->d_assumed + 1);
+                if (rc) return rc;
+                HIP_TRY(ctx, hipMemcpyAsync(ctx->h_fstats + f, ctx->d_fstats + ctx->frames_cap, sizeof(frame_stats), hipMemcpyDeviceToHost, ctx->stream));
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); /* before run_frames() reuses the slot */
+                rc = run_frames(ctx, d, &ctx->p_frames[f], 1, ctx->d_assumed + 1, nullptr, false, (int)ctx->frames_cap, false);
+                if (rc) return rc;
+                HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                redone++;
+                continue;
+            }
             /* the assumption was wrong for this frame: its true floor/ceiling are now
              * known (the fused kernel measured them), so run it again with those */
             assumed_stats *as = ctx->h_assumed + 1;
@@ -1105,6 +1136,7 @@ int h2y_matrix_convert(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3
     memset(&a.sn, 0, sizeof a.sn);
     a.tiles_magic = 0;
     a.redo_count = nullptr;
+    a.low_flag = nullptr;
     a.partial = ctx->d_partial;
     a.assumed = ctx->d_assumed;
     a.pp = pp;

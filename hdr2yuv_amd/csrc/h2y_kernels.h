@@ -60,6 +60,7 @@ struct fused_args {
     uint32_t tiles_magic;     /* floor(2^32 / tiles_per_frame): k_fused_t1's redo list holds frame * tiles + tile */
     float *partial;           /* [n_frames][grid][6] */
     uint32_t *redo_count;     /* k_fused_t1: [n_frames][grid * waves] tiles sent to the redo list, or NULL */
+    uint32_t *low_flag;       /* k_fused_t1 with assumed floor 0 / ceiling 1: [n_frames], kept zero between launches, or NULL */
     const assumed_stats *assumed;
     h2y::pix_params pp;       /* offset/range/norm_identity are filled in-kernel from *assumed */
 };
@@ -85,6 +86,7 @@ struct stats_args {
 struct final_args {
     const float *partial; /* [n_frames][nblk][6] */
     const uint32_t *redo_count; /* [n_frames][nblk] or NULL */
+    uint32_t *low_flag;         /* [n_frames] or NULL: see fused_args; read and cleared */
     int nblk;
     frame_stats *out; /* [n_frames] */
     int is_u16, src_bit_depth;

@@ -644,3 +644,43 @@ def test_tier_steering_on_black_frames(oracle):
         assert names[10] == "k_fused2"               # away again (for 16 batches now)
     finally:
         c.close()
+
+
+def test_subsampled_minimum_cases(oracle):
+    """k_fused_t1 with the assumed floor 0 / ceiling 1 tracks the maximum of every sample but only a
+    subsample of the minimum (row 0, columns 0-1 of every 4x2 tile).  Frames where that is not enough must be
+    noticed and redone with exact statistics: a sample <= -1 off the subsample (floor -1), a frame whose
+    subsample is all >= 1 although other samples are small (floor 0 after all), and both in one batch with
+    ordinary frames."""
+    import torch
+
+    rng = np.random.default_rng(77)
+    w, hh = 256, 64
+    d = h.make_desc(w, hh, dst_depth=12, dst_matrix=h.MATRIX_BT2020NC, resampler=0)
+    od = _to_oracle_desc(d)
+    host = [_rand_planes(rng, w, hh, h.SAMPLE_F32) for _ in range(6)]
+    host[2][1][3 * w + 7] = np.float32(-1.5)            # odd row, column 7: never in the subsample
+    img = [p.reshape(hh, w) for p in host[4]]
+    for p in img:
+        p[0::2, 0::4] = np.float32(1.25)                 # the whole subsample >= 1 ...
+        p[0::2, 1::4] = np.float32(1.5)
+        p[1, 2] = np.float32(0.25)                       # ... but the picture's minimum is not
+    dev_in = [[torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in fr] for fr in host]
+    dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda") for _ in host]
+    c = h.Context(0)
+    try:
+        c.convert_batch(d, dev_in[:2], dev_out[:2])       # establishes the hint floor 0 / ceiling 1
+        for t in dev_out:
+            t.zero_()
+        c.convert_batch_enqueue(d, dev_in, dev_out)
+        assert c.last_kernel_name() == "k_fused_t1"
+        redone = c.batch_finish()
+        assert redone == 2
+        for f in range(len(host)):
+            got = dev_out[f].cpu().numpy().view(np.uint16)
+            assert np.array_equal(got, oracle.convert_frame(od, host[f])), f"frame {f}"
+        # and the next batch still runs on a correct hint (the last frame was ordinary)
+        c.convert_batch(d, dev_in[:2], dev_out[:2])
+        assert np.array_equal(dev_out[1].cpu().numpy().view(np.uint16), oracle.convert_frame(od, host[1]))
+    finally:
+        c.close()

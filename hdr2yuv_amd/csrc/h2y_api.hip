@@ -296,6 +296,21 @@ void t1_end_batch(h2y_ctx *ctx, const h2y_desc *d, const frame_stats *fs, int n)
     } else ctx->t1_skip_len = 0;
 }
 
+/* H2Y_GROUPS=n in the environment caps the number of frame groups (A/B timing; 1 = off) */
+int max_groups()
+{
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("H2Y_GROUPS");
+        v = e ? atoi(e) : 8;
+        if (v < 1) v = 1;
+        int p = 1;
+        while (2 * p <= v && p < 64) p *= 2; /* power of two */
+        v = p;
+    }
+    return v;
+}
+
 /* known: the floor/ceiling the kernels will assume, when the HOST knows them (hint or
  * override); NULL when they only exist in device memory (stats pre-pass). */
 /* H2Y_T1=0 in the environment keeps the binary32 first tier off (A/B timing) */
@@ -380,6 +395,14 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
                                     ctx->stream));
         const int grid = grid_for(ctx, var, (uint64_t)g.chunks * nf);
         const int waves = h2y_fused_threads(var) / 64; /* the fused kernels leave one min/max record per wave */
+        /* frame groups (frame_walk in h2y_kernels.hip): as many as divide both the batch and the grid, up to 8 */
+        int groups = 1;
+        if (h2y_fused_grouped(var))
+            for (int ng = max_groups(); ng > 1; ng >>= 1)
+                if (nf % ng == 0 && grid % ng == 0) {
+                    groups = ng;
+                    break;
+                }
         int rc = ensure(ctx, ctx->d_partial, ctx->partial_cap, (size_t)nf * grid * waves * 6 * sizeof(float));
         if (rc) return rc;
         const bool t1 = var.pipe == 4 || var.pipe == 5;
@@ -408,6 +431,7 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         a.wq_magic = g.wq_magic;
         a.tiles_per_frame = g.tiles;
         a.chunks_per_frame = g.chunks;
+        a.groups = (uint32_t)groups;
         a.table = ctx->d_table;
         a.lut16 = ctx->d_lut16;
         a.table1 = ctx->d_table1;
@@ -428,7 +452,7 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         }
         final_args fa;
         fa.partial = ctx->d_partial;
-        fa.nblk = grid * waves;
+        fa.nblk = grid / groups * waves;
         fa.redo_count = t1 ? ctx->d_redo : nullptr;
         fa.low_flag = approx ? ctx->d_low : nullptr;
         fa.out = ctx->d_fstats + fstats_offset + f0;
@@ -1130,6 +1154,7 @@ int h2y_matrix_convert(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3
     a.wq_magic = g.wq_magic;
     a.tiles_per_frame = g.tiles;
     a.chunks_per_frame = g.chunks;
+    a.groups = 1;
     a.table = ctx->d_table;
     a.lut16 = ctx->d_lut16;
     a.table1 = ctx->d_table1;

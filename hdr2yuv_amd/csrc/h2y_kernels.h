@@ -53,13 +53,15 @@ struct fused_args {
     uint32_t wq_magic;        /* floor(2^32 / wq) */
     uint32_t tiles_per_frame; /* thread-tiles per frame */
     uint32_t chunks_per_frame;
+    uint32_t groups;          /* k_fused2 / k_fused_t1 / k_fused_lut16: the grid works as this many groups of gridDim.x / groups
+                                 blocks, group g on frames g, g + groups, ... (1: every block on every frame); divides gridDim.x */
     const void *table;        /* pq_recA[NREC] then pq_recB[NREC] */
     const float *lut16;       /* k_fused_lut16: PQ of every half in [0,2) */
     const void *table1;       /* k_fused_t1: pq_rec1[H2Y_T1_NREC] */
     h2y::t1_sens sn;          /* k_fused_t1: sensitivity windows */
     uint32_t tiles_magic;     /* floor(2^32 / tiles_per_frame): k_fused_t1's redo list holds frame * tiles + tile */
-    float *partial;           /* [n_frames][grid][6] */
-    uint32_t *redo_count;     /* k_fused_t1: [n_frames][grid * waves] tiles sent to the redo list, or NULL */
+    float *partial;           /* [n_frames][grid / groups][waves][6] (k_fused: [n_frames][grid][6]) */
+    uint32_t *redo_count;     /* k_fused_t1: [n_frames][grid / groups * waves] tiles sent to the redo list, or NULL */
     uint32_t *low_flag;       /* k_fused_t1 with assumed floor 0 / ceiling 1: [n_frames], kept zero between launches, or NULL */
     const assumed_stats *assumed;
     h2y::pix_params pp;       /* offset/range/norm_identity are filled in-kernel from *assumed */
@@ -117,6 +119,7 @@ struct inverse_args {
 
 int h2y_fused_threads(const fused_variant &v);
 const char *h2y_fused_name(const fused_variant &v);
+bool h2y_fused_grouped(const fused_variant &v); /* does the kernel honour fused_args.groups? */
 int h2y_fused_blocks_per_cu(const fused_variant &v);
 hipError_t h2y_launch_fused(const fused_variant &v, int grid, hipStream_t st, const fused_args &a);
 hipError_t h2y_launch_build_lut16(hipStream_t st, const void *table, float *lut);

@@ -26,6 +26,7 @@
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "h2y_math.h"
 #include "h2y_kernels.h"
@@ -418,6 +419,30 @@ __device__ __forceinline__ void row_pack(const pix_params &pp, int row, const ui
         crp[0] = Cr[0] | (Cr[1] << 16); crp[1] = Cr[2] | (Cr[3] << 16);
     }
 }
+/* k_fused_t1's redo pass: store only the parts of tile o that differ from p (what the first tier left there) */
+template <int OUT_KIND>
+__device__ __forceinline__ void tile_store_changes(const frame_io &io, const tile_pos &t, uint32_t W, uint32_t H, const tile_out &o, const tile_out &p)
+{
+    const uint32_t npix = W * H;
+    if ((o.yp0[0] ^ p.yp0[0]) | (o.yp0[1] ^ p.yp0[1])) gstore<u32x2>(io.out, t.i0 >> 2, u32x2{o.yp0[0], o.yp0[1]});
+    if (t.row1 && ((o.yp1[0] ^ p.yp1[0]) | (o.yp1[1] ^ p.yp1[1]))) gstore<u32x2>(io.out, t.i1 >> 2, u32x2{o.yp1[0], o.yp1[1]});
+    if (OUT_KIND == H2Y_OUT_420BOX) {
+        const uint32_t wc = W >> 1;
+        const uint32_t ic = t.rp * wc + (t.x >> 1);
+        const uint32_t ncb = wc * (H >> 1);
+        if (o.cb_box != p.cb_box) gstore<uint32_t>(io.out, (npix + ic) >> 1, o.cb_box);
+        if (o.cr_box != p.cr_box) gstore<uint32_t>(io.out, (npix + ncb + ic) >> 1, o.cr_box);
+    } else {
+        uint16_t *Cbp = OUT_KIND == H2Y_OUT_444 ? io.out + npix : io.tmp_cb;
+        uint16_t *Crp = OUT_KIND == H2Y_OUT_444 ? io.out + 2 * (size_t)npix : io.tmp_cr;
+        if ((o.cbp0[0] ^ p.cbp0[0]) | (o.cbp0[1] ^ p.cbp0[1])) gstore<u32x2>(Cbp, t.i0 >> 2, u32x2{o.cbp0[0], o.cbp0[1]});
+        if ((o.crp0[0] ^ p.crp0[0]) | (o.crp0[1] ^ p.crp0[1])) gstore<u32x2>(Crp, t.i0 >> 2, u32x2{o.crp0[0], o.crp0[1]});
+        if (t.row1) {
+            if ((o.cbp1[0] ^ p.cbp1[0]) | (o.cbp1[1] ^ p.cbp1[1])) gstore<u32x2>(Cbp, t.i1 >> 2, u32x2{o.cbp1[0], o.cbp1[1]});
+            if ((o.crp1[0] ^ p.crp1[0]) | (o.crp1[1] ^ p.crp1[1])) gstore<u32x2>(Crp, t.i1 >> 2, u32x2{o.crp1[0], o.crp1[1]});
+        }
+    }
+}
 template <int OUT_KIND>
 __device__ __forceinline__ void tile_store(const frame_io &io, const tile_pos &t, uint32_t W, uint32_t H, const tile_out &o)
 {
@@ -552,20 +577,55 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
     }
 }
 
+/*
+ * Which frames a block of the loop-form kernels works on, and which chunks of them.
+ *
+ * A wave pays a fixed price per frame (min/max reduction over the wave, frame descriptors, the first
+ * tile's latency: ~230 vector instructions, a third of a tile's), and with every block on every frame
+ * a 4K frame is only four tiles per lane.  So the grid works as a.groups groups of G = gridDim.x /
+ * groups blocks (block b: group b % groups, number b / groups in it); group g takes frames g,
+ * g + groups, ...: the same price, groups times as many tiles per lane and frame.  Within a group,
+ * chunk c of the group's n-th frame belongs to block (n * chunks_per_frame + c) % G, so the blocks of
+ * a group stay level across frames (gbase = n * chunks_per_frame % G, kept incrementally).
+ */
+struct frame_walk {
+    uint32_t G, NG, bi, cpf_mod, gbase;
+    int f;
+    __device__ __forceinline__ void init(const fused_args &a)
+    {
+        NG = a.groups;
+        G = gridDim.x / NG;
+        bi = blockIdx.x / NG;
+        f = (int)(blockIdx.x % NG);
+        cpf_mod = a.chunks_per_frame % G;
+        gbase = 0;
+    }
+    __device__ __forceinline__ bool has_next(const fused_args &a) const { return f + (int)NG < a.n_frames; }
+    __device__ __forceinline__ uint32_t wrap(uint32_t x) const { return x >= G ? x - G : x; } /* x < 2 G */
+    __device__ __forceinline__ uint32_t first_k() const { return wrap(bi + G - gbase); }
+    __device__ __forceinline__ uint32_t k_next_frame() const { return wrap(bi + G - wrap(gbase + cpf_mod)); }
+    __device__ __forceinline__ void advance()
+    {
+        gbase = wrap(gbase + cpf_mod);
+        f += (int)NG;
+    }
+    /* this wave's slot in the per-frame arrays: [frame][block of the group][wave] */
+    __device__ __forceinline__ size_t slot(uint32_t waves) const { return ((size_t)f * G + bi) * waves + threadIdx.x / WAVE; }
+};
+
 /* The branch-free loop forms (k_fused2, k_fused_t1, k_fused_lut16) ask for the next tile while they
  * work on the current one.  Where does this block go after chunk k of frame f: chunk k + G of the same
  * frame, else its first chunk of the next frame (k_next_frame), else nowhere -- then the current tile is
  * simply asked for again (the request is unconditional).  Returns the next tile's position and which
  * frame's planes to read; *have says whether the data requested is the tile the block meets next. */
 template <int THREADS>
-__device__ __forceinline__ tile_pos next_tile(const fused_args &a, int f, uint32_t k, uint32_t k_next_frame, const frame_io &io,
+__device__ __forceinline__ tile_pos next_tile(const fused_args &a, const frame_walk &fw, uint32_t k, uint32_t k_next_frame, const frame_io &io,
                                               const frame_io &io_next, const void *(&src)[3], bool *have)
 {
-    const uint32_t G = gridDim.x;
-    uint32_t k2 = k + G;
+    uint32_t k2 = k + fw.G;
     const bool same = k2 < a.chunks_per_frame;
     if (!same) k2 = k_next_frame;
-    *have = same || (f + 1 < a.n_frames && k2 < a.chunks_per_frame);
+    *have = same || (fw.has_next(a) && k2 < a.chunks_per_frame);
     if (!*have) k2 = k;
 #pragma unroll
     for (int c = 0; c < 3; c++) src[c] = (!same && *have) ? io_next.in[c] : io.in[c];
@@ -602,19 +662,21 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
     const pix_params pp = with_assumed(a.pp, a.assumed);
     __syncthreads();
 
-    const uint32_t W = a.width, H = a.height, G = gridDim.x;
+    const uint32_t W = a.width, H = a.height;
     tile_in v;         /* the tile being worked on; refilled row by row with the next one */
     tile_pos t_cur;    /* and where it is */
     bool have = false; /* v holds the tile this block meets next (uniform) */
     typedef in_traits<IN_KIND> IN;
-    for (int f = 0; f < a.n_frames; f++) {
+    frame_walk fw;
+    for (fw.init(a); fw.f < a.n_frames; fw.advance()) {
+        const int f = fw.f;
+        const uint32_t G = fw.G;
         const frame_io io = uniform_io(a.frames + f);
-        const frame_io io_next = uniform_io(a.frames + (f + 1 < a.n_frames ? f + 1 : f));
+        const frame_io io_next = uniform_io(a.frames + (fw.has_next(a) ? f + (int)fw.NG : f));
         mm6 mm;
         mm.reset();
-        const uint32_t gbase = (uint32_t)(((uint64_t)f * a.chunks_per_frame) % G);
-        const uint32_t k_next_frame = (uint32_t)((blockIdx.x + G - (uint32_t)(((uint64_t)(f + 1) * a.chunks_per_frame) % G)) % G);
-        uint32_t k = (blockIdx.x + G - gbase) % G;
+        const uint32_t k_next_frame = fw.k_next_frame();
+        uint32_t k = fw.first_k();
         if (!have && k < a.chunks_per_frame) {
             t_cur = tile_locate(umin32(k * H2Y_FUSED_THREADS + threadIdx.x, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
             tile_load<IN_KIND>(io, t_cur, v);
@@ -626,7 +688,7 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
             tile_pos t = t_cur;
             t.row1 = true;
             const void *src[3];
-            const tile_pos t2 = next_tile<H2Y_FUSED_THREADS>(a, f, k, k_next_frame, io, io_next, src, &have);
+            const tile_pos t2 = next_tile<H2Y_FUSED_THREADS>(a, fw, k, k_next_frame, io, io_next, src, &have);
 
             tile_out o;
             uint32_t sb[2], sr[2];
@@ -664,7 +726,7 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
             IN::load4(src[2], t2.i1, v.r1);
             t_cur = t2;
         }
-        wave_store_mm(mm, a.partial + (((size_t)f * G + blockIdx.x) * (H2Y_FUSED_THREADS / WAVE) + threadIdx.x / WAVE) * 6);
+        wave_store_mm(mm, a.partial + fw.slot(H2Y_FUSED_THREADS / WAVE) * 6);
     }
 }
 
@@ -692,10 +754,42 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
 #define H2Y_REDO_CAP 128 /* list entries per wave: up to 63 left over plus the 64 one tile can add */
 struct redo_ctx {        /* what redo_pass needs, handed over in LDS so that the call carries two pointers */
     const frame_io *frames;
+    const pq_rec1 *t1;   /* first-tier table (LDS) */
+    t1_sens sn;
     uint32_t *low_flag;  /* [n_frames]: set when a frame holds a sample <= -1 (subsampled minimum, see the tile loop) */
     uint32_t width, height, wq, wq_magic, tiles_per_frame, tiles_magic;
 };
-/* one tile per lane out of the wave's list: entries [first, first + cnt) */
+/* The first tier's result for one tile, by the very instructions of k_fused_t1's loop (same inline
+ * functions, same operands: binary32/64 arithmetic without contraction is deterministic), flags ignored:
+ * the bytes the loop stored provisionally. */
+template <int OUT_KIND, int MODE, int PIPE>
+__device__ __forceinline__ void tile_t1(const pix_params &pp, const t1_sens &sn, const pq_rec1 *t1, const tile_in &v, tile_out &o)
+{
+    uint32_t sb[2], sr[2];
+#pragma unroll
+    for (int row = 0; row < 2; row++) {
+        const float(&gv)[4] = row ? v.g1 : v.g0;
+        const float(&bv)[4] = row ? v.b1 : v.b0;
+        const float(&rv)[4] = row ? v.r1 : v.r0;
+        uint32_t Y[4], Cb[4], Cr[4];
+#pragma unroll
+        for (int col = 0; col < 4; col++) {
+            bool ug, ub, ur;
+            const float g = pix_scale(pq_t1(norm1<PIPE>(pp, 0, gv[col]), t1, &ug), pp.mulY, pp.addY);
+            const float b = pix_scale(pq_t1(norm1<PIPE>(pp, 1, bv[col]), t1, &ub), pp.mulC, pp.addC);
+            const float r = pix_scale(pq_t1(norm1<PIPE>(pp, 2, rv[col]), t1, &ur), pp.mulC, pp.addC);
+            (void)pix_matrix_t1<MODE>(pp, sn, g, b, r, ug | ub | ur, Y[col], Cb[col], Cr[col]);
+        }
+        row_pack<OUT_KIND>(pp, row, Y, Cb, Cr, o, sb, sr);
+    }
+}
+
+/* one tile per lane out of the wave's list: entries [first, first + cnt).
+ * What costs here is not the arithmetic but the scattered stores (partial lines of bytes long evicted
+ * from the caches: measured 1.1 of the 1.9 us per 4K frame the passes took, the six loads 0.45, the
+ * arithmetic 0.1), and most redone tiles come out as the first tier left them (an unsure sample is the
+ * right float half of the time, a sensitive pixel rarely moves): the pass recomputes the first tier's
+ * bytes and stores only the parts that differ. */
 template <int IN_KIND, int OUT_KIND, int MODE, int PIPE>
 __device__ __forceinline__ void redo_pass(const redo_ctx *rc, const pix_params *spp, const pq_recA *sA, const uint32_t *list,
                                                     uint32_t first, uint32_t cnt)
@@ -719,7 +813,13 @@ __device__ __forceinline__ void redo_pass(const redo_ctx *rc, const pix_params *
     }
     tile_out o;
     tile_exact<OUT_KIND, MODE, PIPE>(*spp, spp, sA, sB, v, o);
+#if defined(H2Y_REDO_STOREALL) /* timing experiments only */
     tile_store<OUT_KIND>(io, t, rc->width, rc->height, o);
+#else
+    tile_out p;
+    tile_t1<OUT_KIND, MODE, PIPE>(*spp, rc->sn, rc->t1, v, p);
+    tile_store_changes<OUT_KIND>(io, t, rc->width, rc->height, o, p);
+#endif
 }
 
 template <int IN_KIND, int OUT_KIND, int MODE, int PIPE>
@@ -744,13 +844,15 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
     if (threadIdx.x == 0) {
         s_pp = pp;
         s_rc.frames = a.frames;
+        s_rc.t1 = s_t1;
+        s_rc.sn = a.sn;
         s_rc.low_flag = a.low_flag;
         s_rc.width = a.width; s_rc.height = a.height; s_rc.wq = a.wq; s_rc.wq_magic = a.wq_magic;
         s_rc.tiles_per_frame = a.tiles_per_frame; s_rc.tiles_magic = a.tiles_magic;
     }
     __syncthreads();
 
-    const uint32_t W = a.width, H = a.height, G = gridDim.x;
+    const uint32_t W = a.width, H = a.height;
     const uint32_t lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
     uint32_t *const my_list = s_redo[wave];
     uint32_t n_redo = 0; /* entries in my_list (uniform over the wave) */
@@ -771,16 +873,18 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
     tile_pos t_cur;    /* and where it is */
     bool have = false; /* v holds the tile this block meets next (uniform) */
     typedef in_traits<IN_KIND> IN;
-    for (int f = 0; f < a.n_frames; f++) {
+    frame_walk fw;
+    for (fw.init(a); fw.f < a.n_frames; fw.advance()) {
+        const int f = fw.f;
+        const uint32_t G = fw.G;
         const frame_io io = uniform_io(a.frames + f);
-        const frame_io io_next = uniform_io(a.frames + (f + 1 < a.n_frames ? f + 1 : f)); /* for the prefetch across the frame boundary */
+        const frame_io io_next = uniform_io(a.frames + (fw.has_next(a) ? f + (int)fw.NG : f)); /* for the prefetch across the frame boundary */
         mm6 mm;
         mm.reset();
-        const uint32_t gbase = (uint32_t)(((uint64_t)f * a.chunks_per_frame) % G);
-        const uint32_t k_next_frame = (uint32_t)((blockIdx.x + G - (uint32_t)(((uint64_t)(f + 1) * a.chunks_per_frame) % G)) % G);
+        const uint32_t k_next_frame = fw.k_next_frame();
         const uint32_t id_base = (uint32_t)f * a.tiles_per_frame;
         uint32_t flagged_f = 0; /* tiles of this frame this wave sent to the list (the host steers by their share) */
-        uint32_t k = (blockIdx.x + G - gbase) % G;
+        uint32_t k = fw.first_k();
         while (k < a.chunks_per_frame) {
             if (!have) { /* nothing on its way (first tile of the launch, or a block that skipped frames) */
                 t_cur = tile_locate(umin32(k * H2Y_T1_THREADS + threadIdx.x, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
@@ -796,7 +900,7 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
                 tile_pos t = t_cur; /* located one iteration ago, as the prefetch target */
                 t.row1 = true;
                 const void *src[3];
-                const tile_pos t2 = next_tile<H2Y_T1_THREADS>(a, f, k, k_next_frame, io, io_next, src, &have);
+                const tile_pos t2 = next_tile<H2Y_T1_THREADS>(a, fw, k, k_next_frame, io, io_next, src, &have);
 
                 tile_out o;
                 uint32_t sb[2], sr[2]; /* 2x2 box: chroma sums of the two blocks */
@@ -868,12 +972,14 @@ if (PIPE == H2Y_PIPE_PQ_IDENT) {
             }
             if (n_redo >= WAVE) { /* 64 tiles to redo: one per lane */
                 n_redo -= WAVE;
+#ifndef H2Y_SKIP_REDO /* timing experiments only: what do the passes cost? */
                 redo_pass<IN_KIND, OUT_KIND, MODE, PIPE>(&s_rc, &s_pp, s_t2, my_list, n_redo, WAVE);
                 have = false; /* the prefetched tile is not carried through the pass (registers): it is asked for again */
+#endif
             }
         }
-        wave_store_mm(mm, a.partial + (((size_t)f * G + blockIdx.x) * (H2Y_T1_THREADS / WAVE) + threadIdx.x / WAVE) * 6);
-        if (a.redo_count && lane == 0) a.redo_count[((size_t)f * G + blockIdx.x) * (H2Y_T1_THREADS / WAVE) + wave] = flagged_f;
+        wave_store_mm(mm, a.partial + fw.slot(H2Y_T1_THREADS / WAVE) * 6);
+        if (a.redo_count && lane == 0) a.redo_count[fw.slot(H2Y_T1_THREADS / WAVE)] = flagged_f;
     }
     if (n_redo) redo_pass<IN_KIND, OUT_KIND, MODE, PIPE>(&s_rc, &s_pp, s_t2, my_list, 0u, n_redo);
     (void)lane;
@@ -919,15 +1025,18 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
     if (threadIdx.x == 0) s_pp = pp;
     __syncthreads();
 
-    const uint32_t W = a.width, H = a.height, G = gridDim.x;
+    const uint32_t W = a.width, H = a.height;
     /* the loop form of k_fused_t1: row-wise tiles, rolling prefetch (8-byte loads: four halves), one
      * basic block of memory operations; even height (the host sends odd heights to k_fused) */
     u32x2 raw[3][2];   /* the tile being worked on, raw halves: [plane][row], four samples each */
     tile_pos t_cur;
     bool have = false;
-    for (int f = 0; f < a.n_frames; f++) {
+    frame_walk fw;
+    for (fw.init(a); fw.f < a.n_frames; fw.advance()) {
+        const int f = fw.f;
+        const uint32_t G = fw.G;
         const frame_io io = uniform_io(a.frames + f);
-        const frame_io io_next = uniform_io(a.frames + (f + 1 < a.n_frames ? f + 1 : f));
+        const frame_io io_next = uniform_io(a.frames + (fw.has_next(a) ? f + (int)fw.NG : f));
         /* packed-half accumulators: {min, max} x plane, two halves per dword */
         uint32_t mn[3], mx[3];
 #pragma unroll
@@ -935,9 +1044,8 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
             mn[c] = 0x7C007C00u; /* +inf stands in for FLT_MAX (common.cpp:118): no finite or infinite sample is "< FLT_MAX" unless it is finite */
             mx[c] = 0x00000000u; /* +0: FLT_MIN (1.2e-38) is below the smallest half; (int) of either is 0 */
         }
-        const uint32_t gbase = (uint32_t)(((uint64_t)f * a.chunks_per_frame) % G);
-        const uint32_t k_next_frame = (uint32_t)((blockIdx.x + G - (uint32_t)(((uint64_t)(f + 1) * a.chunks_per_frame) % G)) % G);
-        uint32_t k = (blockIdx.x + G - gbase) % G;
+        const uint32_t k_next_frame = fw.k_next_frame();
+        uint32_t k = fw.first_k();
         if (!have && k < a.chunks_per_frame) {
             t_cur = tile_locate(umin32(k * H2Y_FUSED_THREADS + threadIdx.x, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
 #pragma unroll
@@ -953,7 +1061,7 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
             tile_pos t = t_cur;
             t.row1 = true;
             const void *src[3];
-            const tile_pos t2 = next_tile<H2Y_FUSED_THREADS>(a, f, k, k_next_frame, io, io_next, src, &have);
+            const tile_pos t2 = next_tile<H2Y_FUSED_THREADS>(a, fw, k, k_next_frame, io, io_next, src, &have);
             tile_out o;
             uint32_t sb[2], sr[2];
 #pragma unroll
@@ -1003,7 +1111,7 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
             mm.lo[c] = mm.lo[c] > 65504.0f ? 3.402823466e+38f : mm.lo[c]; /* still +inf: no sample was below FLT_MAX */
             mm.hi[c] = mm.hi[c] <= 0.0f ? 1.175494351e-38f : mm.hi[c];
         }
-        wave_store_mm(mm, a.partial + (((size_t)f * G + blockIdx.x) * (H2Y_FUSED_THREADS / WAVE) + threadIdx.x / WAVE) * 6);
+        wave_store_mm(mm, a.partial + fw.slot(H2Y_FUSED_THREADS / WAVE) * 6);
     }
 }
 
@@ -1430,6 +1538,11 @@ const char *h2y_fused_name(const fused_variant &v)
     if (v.pipe == 3) return "k_fused_lut16";
     if (v.pipe == 4 || v.pipe == 5) return "k_fused_t1";
     return ((v.pipe == 1 || v.pipe == 2 || v.pipe == H2Y_PIPE_NONE) && v.even_h && (v.mode == H2Y_MODE_YCBCR || v.mode == H2Y_MODE_YDZDX)) ? "k_fused2" : "k_fused";
+}
+bool h2y_fused_grouped(const fused_variant &v)
+{
+    const char *n = h2y_fused_name(v); /* the loop-form kernels: k_fused2, k_fused_t1, k_fused_lut16 */
+    return !strcmp(n, "k_fused2") || !strcmp(n, "k_fused_t1") || !strcmp(n, "k_fused_lut16");
 }
 int h2y_fused_threads(const fused_variant &v) { return (v.pipe == 4 || v.pipe == 5) ? H2Y_T1_THREADS : H2Y_FUSED_THREADS; }
 

@@ -684,3 +684,55 @@ def test_subsampled_minimum_cases(oracle):
         assert np.array_equal(dev_out[1].cpu().numpy().view(np.uint16), oracle.convert_frame(od, host[1]))
     finally:
         c.close()
+
+
+@pytest.mark.parametrize("kind,n,w,hh", [("f32", 8, 512, 96), ("f32", 16, 1024, 540), ("f32", 12, 256, 36), ("f32", 24, 64, 8),
+                                         ("f16", 8, 512, 96), ("u16", 8, 512, 96), ("f32_444", 8, 260 * 4, 66)])
+def test_frame_groups(oracle, kind, n, w, hh):
+    """Batches whose length is a multiple of 2/4/8: the loop-form kernels split the grid into that many
+    groups, each walking every 8th (4th, 2nd) frame (frame_walk).  Frames differ in content, some have
+    black bars (dense redo lists), one breaks the statistics assumption (redone afterwards); per-frame
+    statistics land in the right frame's slot or the redo would hit the wrong frame."""
+    import torch
+
+    rng = np.random.default_rng(9000 + n + w)
+    if kind == "f16":
+        d = h.make_desc(w, hh, sample=h.SAMPLE_F16, dst_depth=10, dst_matrix=h.MATRIX_BT2020NC, resampler=0)
+    elif kind == "u16":
+        d = h.make_desc(w, hh, sample=h.SAMPLE_U16, src_depth=16, dst_depth=10, dst_matrix=h.MATRIX_BT2020NC, resampler=0,
+                        src_transfer=16, dst_transfer=16)
+    elif kind == "f32_444":
+        d = h.make_desc(w, hh, dst_depth=12, dst_matrix=h.MATRIX_YDZDX, chroma=h.CHROMA_444)
+    else:
+        d = h.make_desc(w, hh, dst_depth=12, dst_matrix=h.MATRIX_BT2020NC, resampler=0)
+    host = []
+    for k in range(n):
+        if kind == "u16":
+            planes = [rng.integers(0, 65536, w * hh, dtype=np.uint16) for _ in range(3)]
+        else:
+            planes = [rng.uniform(0.0, 1.0, w * hh).astype(np.float32) for _ in range(3)]
+            for p in planes:
+                p[(11 * k) % 50] = 1.0
+                if k % 5 == 2:  # bars
+                    p[: (hh // 8) * w] = 0.0
+            if k == n - 3:
+                planes[2][w + 1] = np.float32(2.25)  # ceiling 2 in this frame only
+            if kind == "f16":
+                planes = [p.astype(np.float16).view(np.uint16) for p in planes]
+        host.append(planes)
+    as_dev = (lambda p: torch.from_numpy(np.ascontiguousarray(p).view(np.int16)).cuda()) if kind in ("f16", "u16") else \
+             (lambda p: torch.from_numpy(np.ascontiguousarray(p)).cuda())
+    dev_in = [[as_dev(p) for p in fr] for fr in host]
+    fresh = h.Context(0)
+    try:
+        od = _to_oracle_desc(d)
+        want = [oracle.convert_frame(od, fr) for fr in host]
+        for rnd in range(2):  # second round: hint known, the first-tier / table kernels run
+            dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda") for _ in host]
+            torch.cuda.synchronize()
+            fresh.convert_batch(d, dev_in, dev_out)
+            for f in range(n):
+                got = dev_out[f].cpu().numpy().view(np.uint16)
+                assert np.array_equal(got, want[f]), f"round {rnd} frame {f}: {np.count_nonzero(got != want[f])} samples differ"
+    finally:
+        fresh.close()

@@ -181,30 +181,34 @@ template <int KIND> struct in_traits;
 template <> struct in_traits<H2Y_IN_F32> {
     typedef float T;
     /* i: sample index, a multiple of 4 (16-byte aligned planes) */
-    template <typename I> static __device__ __forceinline__ void load4(const void *p, I i, float v[4])
+    template <typename I> static __device__ __forceinline__ void load4(const void *p, I i, float v[4]) { load4q(p, i >> 2, v); }
+    /* q: quad index (sample index / 4) */
+    template <typename I> static __device__ __forceinline__ void load4q(const void *p, I q4, float v[4])
     {
-        const f32x4 q = gload<f32x4>(p, i >> 2);
+        const f32x4 q = gload<f32x4>(p, q4);
         v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
     }
     template <typename I> static __device__ __forceinline__ float load1(const void *p, I i) { return gload<float>(p, i); }
 };
 template <> struct in_traits<H2Y_IN_F16> {
     typedef _Float16 T;
-    template <typename I> static __device__ __forceinline__ void load4(const void *p, I i, float v[4])
+    template <typename I> static __device__ __forceinline__ void load4(const void *p, I i, float v[4]) { load4q(p, i >> 2, v); }
+    template <typename I> static __device__ __forceinline__ void load4q(const void *p, I q4, float v[4])
     {
         /* exr.cpp:233-235: half widened to float, exact */
         typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-        const h4 q = gload<h4>(p, i >> 2);
+        const h4 q = gload<h4>(p, q4);
         v[0] = (float)q.x; v[1] = (float)q.y; v[2] = (float)q.z; v[3] = (float)q.w;
     }
     template <typename I> static __device__ __forceinline__ float load1(const void *p, I i) { return (float)gload<_Float16>(p, i); }
 };
 template <> struct in_traits<H2Y_IN_U16> {
     typedef uint16_t T;
-    template <typename I> static __device__ __forceinline__ void load4(const void *p, I i, float v[4])
+    template <typename I> static __device__ __forceinline__ void load4(const void *p, I i, float v[4]) { load4q(p, i >> 2, v); }
+    template <typename I> static __device__ __forceinline__ void load4q(const void *p, I q4, float v[4])
     {
         /* convert.cpp:989-994: (float) of the unsigned short */
-        const u32x2 q = gload<u32x2>(p, i >> 2);
+        const u32x2 q = gload<u32x2>(p, q4);
         v[0] = (float)(q.x & 0xFFFFu); v[1] = (float)(q.x >> 16);
         v[2] = (float)(q.y & 0xFFFFu); v[3] = (float)(q.y >> 16);
     }
@@ -328,21 +332,23 @@ template <int THREADS> __device__ __forceinline__ void stage_table(const void *t
 }
 
 /* ---- the thread tile: 4 columns x 2 rows ------------------------------- */
+/* Positions are kept in QUADS (four samples: one 16-byte load of floats, one 8-byte store of code values):
+ * tile tt = rp * WQ + cg (row pair, column group; WQ = W / 4) starts at quad q0 = 2 rp WQ + cg = 2 tt - cg,
+ * and its two 4:2:0 chroma samples are dword tt of the chroma plane -- only cg = tt mod WQ costs a division. */
 struct tile_pos {
-    uint32_t rp, x; /* row pair, first column */
-    uint32_t i0, i1; /* sample index of row 0 / row 1 (row 1 == row 0 when the picture ends); pictures hold < 2^28 samples */
+    uint32_t tt;     /* tile number within the frame */
+    uint32_t q0, q1; /* quad index of row 0 / row 1 (row 1 == row 0 when the picture ends); pictures hold < 2^28 samples */
     bool row1;
 };
 __device__ __forceinline__ tile_pos tile_locate(uint32_t tt, uint32_t W, uint32_t H, uint32_t WQ, uint32_t magic)
 {
     tile_pos t;
     uint32_t cg;
-    t.rp = udiv_magic(tt, WQ, magic, cg);
-    t.x = cg * 4;
-    const uint32_t y = t.rp * 2;
-    t.row1 = (y + 1) < H;
-    t.i0 = y * W + t.x;
-    t.i1 = t.row1 ? t.i0 + W : t.i0;
+    (void)udiv_magic(tt, WQ, magic, cg);
+    t.tt = tt;
+    t.q0 = 2u * tt - cg;
+    t.row1 = tt < WQ * (H >> 1); /* odd height: the last row of tiles has one picture row */
+    t.q1 = t.row1 ? t.q0 + WQ : t.q0;
     return t;
 }
 struct tile_in {
@@ -351,12 +357,12 @@ struct tile_in {
 template <int IN_KIND> __device__ __forceinline__ void tile_load(const frame_io &io, const tile_pos &t, tile_in &v)
 {
     typedef in_traits<IN_KIND> IN;
-    IN::load4(io.in[0], t.i0, v.g0);
-    IN::load4(io.in[1], t.i0, v.b0);
-    IN::load4(io.in[2], t.i0, v.r0);
-    IN::load4(io.in[0], t.i1, v.g1);
-    IN::load4(io.in[1], t.i1, v.b1);
-    IN::load4(io.in[2], t.i1, v.r1);
+    IN::load4q(io.in[0], t.q0, v.g0);
+    IN::load4q(io.in[1], t.q0, v.b0);
+    IN::load4q(io.in[2], t.q0, v.r0);
+    IN::load4q(io.in[0], t.q1, v.g1);
+    IN::load4q(io.in[1], t.q1, v.b1);
+    IN::load4q(io.in[2], t.q1, v.r1);
 }
 /* packed results of a tile, ready to store */
 struct tile_out {
@@ -389,28 +395,29 @@ __device__ __forceinline__ void tile_pack(const pix_params &pp, int jb, const ui
     }
 }
 /* the same packing one picture row (four pixels) at a time; sb/sr carry the 2x2 box sums from row 0 to row 1 */
-template <int OUT_KIND>
+/* NOSHIFT: write_yuv's down shift is known to be zero (float input: the temporary picture has the output's depth) */
+template <int OUT_KIND, bool NOSHIFT = false>
 __device__ __forceinline__ void row_pack(const pix_params &pp, int row, const uint32_t (&Y)[4], uint32_t (&Cb)[4], uint32_t (&Cr)[4],
                                          tile_out &o, uint32_t (&sb)[2], uint32_t (&sr)[2])
 {
     uint32_t(&yp)[2] = row ? o.yp1 : o.yp0;
-    yp[0] = pix_yuv_clamp(pp, Y[0], false) | (pix_yuv_clamp(pp, Y[1], false) << 16);
-    yp[1] = pix_yuv_clamp(pp, Y[2], false) | (pix_yuv_clamp(pp, Y[3], false) << 16);
+    yp[0] = pix_yuv_clamp<NOSHIFT>(pp, Y[0], false) | (pix_yuv_clamp<NOSHIFT>(pp, Y[1], false) << 16);
+    yp[1] = pix_yuv_clamp<NOSHIFT>(pp, Y[2], false) | (pix_yuv_clamp<NOSHIFT>(pp, Y[3], false) << 16);
     if (OUT_KIND == H2Y_OUT_420BOX) {
         if (row == 0) {
             sb[0] = Cb[0] + Cb[1]; sb[1] = Cb[2] + Cb[3];
             sr[0] = Cr[0] + Cr[1]; sr[1] = Cr[2] + Cr[3];
         } else {
             /* convert.cpp:157-160: (a+b+c+d)/4, unsigned truncation; then write_yuv's clamp */
-            o.cb_box = pix_box_clamp(pp, sb[0] + Cb[0] + Cb[1]) | (pix_box_clamp(pp, sb[1] + Cb[2] + Cb[3]) << 16);
-            o.cr_box = pix_box_clamp(pp, sr[0] + Cr[0] + Cr[1]) | (pix_box_clamp(pp, sr[1] + Cr[2] + Cr[3]) << 16);
+            o.cb_box = pix_box_clamp<NOSHIFT>(pp, sb[0] + Cb[0] + Cb[1]) | (pix_box_clamp<NOSHIFT>(pp, sb[1] + Cb[2] + Cb[3]) << 16);
+            o.cr_box = pix_box_clamp<NOSHIFT>(pp, sr[0] + Cr[0] + Cr[1]) | (pix_box_clamp<NOSHIFT>(pp, sr[1] + Cr[2] + Cr[3]) << 16);
         }
     } else {
         if (OUT_KIND == H2Y_OUT_444) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                Cb[q] = pix_yuv_clamp(pp, Cb[q], true);
-                Cr[q] = pix_yuv_clamp(pp, Cr[q], true);
+                Cb[q] = pix_yuv_clamp<NOSHIFT>(pp, Cb[q], true);
+                Cr[q] = pix_yuv_clamp<NOSHIFT>(pp, Cr[q], true);
             }
         }
         uint32_t(&cbp)[2] = row ? o.cbp1 : o.cbp0;
@@ -419,51 +426,49 @@ __device__ __forceinline__ void row_pack(const pix_params &pp, int row, const ui
         crp[0] = Cr[0] | (Cr[1] << 16); crp[1] = Cr[2] | (Cr[3] << 16);
     }
 }
+/* offsets in units of the store (u32x2: a quad of code values; dword: two 4:2:0 chroma samples) from
+ * the start of the frame's output: < 2^32 bytes.  W % 4 == 0, so W * H and the chroma plane's size are even. */
 /* k_fused_t1's redo pass: store only the parts of tile o that differ from p (what the first tier left there) */
 template <int OUT_KIND>
 __device__ __forceinline__ void tile_store_changes(const frame_io &io, const tile_pos &t, uint32_t W, uint32_t H, const tile_out &o, const tile_out &p)
 {
     const uint32_t npix = W * H;
-    if ((o.yp0[0] ^ p.yp0[0]) | (o.yp0[1] ^ p.yp0[1])) gstore<u32x2>(io.out, t.i0 >> 2, u32x2{o.yp0[0], o.yp0[1]});
-    if (t.row1 && ((o.yp1[0] ^ p.yp1[0]) | (o.yp1[1] ^ p.yp1[1]))) gstore<u32x2>(io.out, t.i1 >> 2, u32x2{o.yp1[0], o.yp1[1]});
+    if ((o.yp0[0] ^ p.yp0[0]) | (o.yp0[1] ^ p.yp0[1])) gstore<u32x2>(io.out, t.q0, u32x2{o.yp0[0], o.yp0[1]});
+    if (t.row1 && ((o.yp1[0] ^ p.yp1[0]) | (o.yp1[1] ^ p.yp1[1]))) gstore<u32x2>(io.out, t.q1, u32x2{o.yp1[0], o.yp1[1]});
     if (OUT_KIND == H2Y_OUT_420BOX) {
-        const uint32_t wc = W >> 1;
-        const uint32_t ic = t.rp * wc + (t.x >> 1);
-        const uint32_t ncb = wc * (H >> 1);
-        if (o.cb_box != p.cb_box) gstore<uint32_t>(io.out, (npix + ic) >> 1, o.cb_box);
-        if (o.cr_box != p.cr_box) gstore<uint32_t>(io.out, (npix + ncb + ic) >> 1, o.cr_box);
+        const uint32_t ncb = (W >> 1) * (H >> 1);
+        if (o.cb_box != p.cb_box) gstore<uint32_t>(io.out, (npix >> 1) + t.tt, o.cb_box);
+        if (o.cr_box != p.cr_box) gstore<uint32_t>(io.out, ((npix + ncb) >> 1) + t.tt, o.cr_box);
     } else {
         uint16_t *Cbp = OUT_KIND == H2Y_OUT_444 ? io.out + npix : io.tmp_cb;
         uint16_t *Crp = OUT_KIND == H2Y_OUT_444 ? io.out + 2 * (size_t)npix : io.tmp_cr;
-        if ((o.cbp0[0] ^ p.cbp0[0]) | (o.cbp0[1] ^ p.cbp0[1])) gstore<u32x2>(Cbp, t.i0 >> 2, u32x2{o.cbp0[0], o.cbp0[1]});
-        if ((o.crp0[0] ^ p.crp0[0]) | (o.crp0[1] ^ p.crp0[1])) gstore<u32x2>(Crp, t.i0 >> 2, u32x2{o.crp0[0], o.crp0[1]});
+        if ((o.cbp0[0] ^ p.cbp0[0]) | (o.cbp0[1] ^ p.cbp0[1])) gstore<u32x2>(Cbp, t.q0, u32x2{o.cbp0[0], o.cbp0[1]});
+        if ((o.crp0[0] ^ p.crp0[0]) | (o.crp0[1] ^ p.crp0[1])) gstore<u32x2>(Crp, t.q0, u32x2{o.crp0[0], o.crp0[1]});
         if (t.row1) {
-            if ((o.cbp1[0] ^ p.cbp1[0]) | (o.cbp1[1] ^ p.cbp1[1])) gstore<u32x2>(Cbp, t.i1 >> 2, u32x2{o.cbp1[0], o.cbp1[1]});
-            if ((o.crp1[0] ^ p.crp1[0]) | (o.crp1[1] ^ p.crp1[1])) gstore<u32x2>(Crp, t.i1 >> 2, u32x2{o.crp1[0], o.crp1[1]});
+            if ((o.cbp1[0] ^ p.cbp1[0]) | (o.cbp1[1] ^ p.cbp1[1])) gstore<u32x2>(Cbp, t.q1, u32x2{o.cbp1[0], o.cbp1[1]});
+            if ((o.crp1[0] ^ p.crp1[0]) | (o.crp1[1] ^ p.crp1[1])) gstore<u32x2>(Crp, t.q1, u32x2{o.crp1[0], o.crp1[1]});
         }
     }
 }
 template <int OUT_KIND>
 __device__ __forceinline__ void tile_store(const frame_io &io, const tile_pos &t, uint32_t W, uint32_t H, const tile_out &o)
 {
-    /* offsets in units of u32x2 (four samples) from the start of the frame's output: < 2^32 bytes */
     const uint32_t npix = W * H;
-    gstore<u32x2>(io.out, t.i0 >> 2, u32x2{o.yp0[0], o.yp0[1]});
-    if (t.row1) gstore<u32x2>(io.out, t.i1 >> 2, u32x2{o.yp1[0], o.yp1[1]});
+    gstore<u32x2>(io.out, t.q0, u32x2{o.yp0[0], o.yp0[1]});
+    if (t.row1) gstore<u32x2>(io.out, t.q1, u32x2{o.yp1[0], o.yp1[1]});
     if (OUT_KIND == H2Y_OUT_420BOX) {
-        const uint32_t wc = W >> 1;
-        const uint32_t ic = t.rp * wc + (t.x >> 1); /* even: two chroma samples per tile */
-        const uint32_t ncb = wc * (H >> 1);
-        gstore<uint32_t>(io.out, (npix + ic) >> 1, o.cb_box);
-        gstore<uint32_t>(io.out, (npix + ncb + ic) >> 1, o.cr_box);
+        /* the tile's two chroma samples: index rp * (W / 2) + x / 2 = 2 tt, i.e. dword tt of each plane */
+        const uint32_t ncb = (W >> 1) * (H >> 1);
+        gstore<uint32_t>(io.out, (npix >> 1) + t.tt, o.cb_box);
+        gstore<uint32_t>(io.out, ((npix + ncb) >> 1) + t.tt, o.cr_box);
     } else {
         uint16_t *Cbp = OUT_KIND == H2Y_OUT_444 ? io.out + npix : io.tmp_cb;
         uint16_t *Crp = OUT_KIND == H2Y_OUT_444 ? io.out + 2 * (size_t)npix : io.tmp_cr;
-        gstore<u32x2>(Cbp, t.i0 >> 2, u32x2{o.cbp0[0], o.cbp0[1]});
-        gstore<u32x2>(Crp, t.i0 >> 2, u32x2{o.crp0[0], o.crp0[1]});
+        gstore<u32x2>(Cbp, t.q0, u32x2{o.cbp0[0], o.cbp0[1]});
+        gstore<u32x2>(Crp, t.q0, u32x2{o.crp0[0], o.crp0[1]});
         if (t.row1) {
-            gstore<u32x2>(Cbp, t.i1 >> 2, u32x2{o.cbp1[0], o.cbp1[1]});
-            gstore<u32x2>(Crp, t.i1 >> 2, u32x2{o.crp1[0], o.crp1[1]});
+            gstore<u32x2>(Cbp, t.q1, u32x2{o.cbp1[0], o.cbp1[1]});
+            gstore<u32x2>(Crp, t.q1, u32x2{o.crp1[0], o.crp1[1]});
         }
     }
 }
@@ -712,18 +717,18 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
                     /* the careful form of the matrix: IEEE divisions, the reference's NaN conversions */
                     if (__builtin_expect(um | odd, 0)) pix_matrix<MODE, true>(pp, g, b, r, Y[col], Cb[col], Cr[col], &um);
                 }
-                row_pack<OUT_KIND>(pp, row, Y, Cb, Cr, o, sb, sr);
+                row_pack<OUT_KIND, IN_KIND != H2Y_IN_U16>(pp, row, Y, Cb, Cr, o, sb, sr);
                 if (row == 0) {
-                    IN::load4(src[0], t2.i0, v.g0);
-                    IN::load4(src[1], t2.i0, v.b0);
-                    IN::load4(src[2], t2.i0, v.r0);
+                    IN::load4q(src[0], t2.q0, v.g0);
+                    IN::load4q(src[1], t2.q0, v.b0);
+                    IN::load4q(src[2], t2.q0, v.r0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             tile_store<OUT_KIND>(io, t, W, H, o);
-            IN::load4(src[0], t2.i1, v.g1);
-            IN::load4(src[1], t2.i1, v.b1);
-            IN::load4(src[2], t2.i1, v.r1);
+            IN::load4q(src[0], t2.q1, v.g1);
+            IN::load4q(src[1], t2.q1, v.b1);
+            IN::load4q(src[2], t2.q1, v.r1);
             t_cur = t2;
         }
         wave_store_mm(mm, a.partial + fw.slot(H2Y_FUSED_THREADS / WAVE) * 6);
@@ -780,7 +785,7 @@ __device__ __forceinline__ void tile_t1(const pix_params &pp, const t1_sens &sn,
             const float r = pix_scale(pq_t1(norm1<PIPE>(pp, 2, rv[col]), t1, &ur), pp.mulC, pp.addC);
             (void)pix_matrix_t1<MODE>(pp, sn, g, b, r, ug | ub | ur, Y[col], Cb[col], Cr[col]);
         }
-        row_pack<OUT_KIND>(pp, row, Y, Cb, Cr, o, sb, sr);
+        row_pack<OUT_KIND, true>(pp, row, Y, Cb, Cr, o, sb, sr);
     }
 }
 
@@ -840,7 +845,7 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
     t1_sens sn = a.sn;
     /* the two window constants selected per pixel (v_cndmask_b32 wants one operand in a vector register):
      * kept in registers for the whole kernel instead of being moved there for every pixel */
-    asm volatile("" : "+v"(sn.c_lo), "+v"(sn.c_span));
+    asm volatile("" : "+v"(sn.a_lo), "+v"(sn.a_hi));
     if (threadIdx.x == 0) {
         s_pp = pp;
         s_rc.frames = a.frames;
@@ -904,7 +909,7 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
 
                 tile_out o;
                 uint32_t sb[2], sr[2]; /* 2x2 box: chroma sums of the two blocks */
-                uint32_t redo_n = 0;
+                uint64_t redo_m = 0; /* lanes whose tile holds a pixel to redo: the guards' own lane masks, ORed in scalar registers */
 #pragma unroll
                 for (int row = 0; row < 2; row++) {
                     const float(&gv)[4] = row ? v.g1 : v.g0;
@@ -935,24 +940,26 @@ if (PIPE == H2Y_PIPE_PQ_IDENT) {
                         const float g = pix_scale(pq_t1(Gn, s_t1, &ug), pp.mulY, pp.addY);
                         const float b = pix_scale(pq_t1(Bn, s_t1, &ub), pp.mulC, pp.addC);
                         const float r = pix_scale(pq_t1(Rn, s_t1, &ur), pp.mulC, pp.addC);
-                        redo_n += pix_matrix_t1<MODE>(pp, sn, g, b, r, ug | ub | ur, Y[col], Cb[col], Cr[col]) ? 1u : 0u;
-                        /* pin the count here: left alone, the compiler postpones every pixel's guard arithmetic
+                        bool ra, rb;
+                        pix_matrix_t1<MODE>(pp, sn, g, b, r, ug | ub | ur, Y[col], Cb[col], Cr[col], &ra, &rb);
+                        redo_m |= __builtin_amdgcn_ballot_w64(ra) | __builtin_amdgcn_ballot_w64(rb); /* a ballot of a compare is the compare's own result */
+                        /* pin the mask here: left alone, the compiler postpones every pixel's guard arithmetic
                          * to the end of the tile and keeps its operands alive until then (register spills) */
-                        asm volatile("" : "+v"(redo_n));
+                        asm volatile("" : "+s"(redo_m));
                     }
-                    row_pack<OUT_KIND>(pp, row, Y, Cb, Cr, o, sb, sr);
+                    row_pack<OUT_KIND, true>(pp, row, Y, Cb, Cr, o, sb, sr);
                     if (row == 0) { /* row 0 of the next tile, into the registers just read for the last time */
-                        IN::load4(src[0], t2.i0, v.g0);
-                        IN::load4(src[1], t2.i0, v.b0);
-                        IN::load4(src[2], t2.i0, v.r0);
+                        IN::load4q(src[0], t2.q0, v.g0);
+                        IN::load4q(src[1], t2.q0, v.b0);
+                        IN::load4q(src[2], t2.q0, v.r0);
                         /* nothing of row 1 may move up past this point: its data is the youngest request */
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
                 tile_store<OUT_KIND>(io, t, W, H, o);
-                IN::load4(src[0], t2.i1, v.g1);
-                IN::load4(src[1], t2.i1, v.b1);
-                IN::load4(src[2], t2.i1, v.r1);
+                IN::load4q(src[0], t2.q1, v.g1);
+                IN::load4q(src[1], t2.q1, v.b1);
+                IN::load4q(src[2], t2.q1, v.r1);
                 t_cur = t2;
                 /* tiles to redo (a few lanes of about one wave in four at 12 bits; whole waves on black
                  * bars) go to the wave's list: position = entries so far + flagged lanes below this one */
@@ -961,8 +968,8 @@ if (PIPE == H2Y_PIPE_PQ_IDENT) {
                      * again -- possibly after the tile's owner already replaced them with the exact ones.  So
                      * they list the tile too: the last store to a flagged tile is then always a redo_pass()
                      * store (a wave's own redo follows its own provisional store). */
-                    const bool flagged = redo_n != 0;
-                    const uint64_t m = __ballot(flagged);
+                    const uint64_t m = redo_m;
+                    const bool flagged = ((m >> lane) & 1u) != 0;
                     const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                     /* unflagged lanes write to the spare last slot: no branch in the loop body */
                     my_list[flagged ? n_redo + below : (uint32_t)(H2Y_REDO_CAP - 1)] = id_base + umin32(tt, a.tiles_per_frame - 1u);
@@ -1050,8 +1057,8 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
             t_cur = tile_locate(umin32(k * H2Y_FUSED_THREADS + threadIdx.x, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                raw[c][0] = gload<u32x2>(io.in[c], t_cur.i0 >> 2);
-                raw[c][1] = gload<u32x2>(io.in[c], t_cur.i1 >> 2);
+                raw[c][0] = gload<u32x2>(io.in[c], t_cur.q0);
+                raw[c][1] = gload<u32x2>(io.in[c], t_cur.q1);
             }
 #pragma unroll
             for (int c = 0; c < 3; c++)
@@ -1089,16 +1096,16 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
                         Y[col] = c.y; Cb[col] = c.cb; Cr[col] = c.cr;
                     }
                 }
-                row_pack<OUT_KIND>(pp, row, Y, Cb, Cr, o, sb, sr);
+                row_pack<OUT_KIND, true>(pp, row, Y, Cb, Cr, o, sb, sr);
                 if (row == 0) {
 #pragma unroll
-                    for (int c = 0; c < 3; c++) raw[c][0] = gload<u32x2>(src[c], t2.i0 >> 2);
+                    for (int c = 0; c < 3; c++) raw[c][0] = gload<u32x2>(src[c], t2.q0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             tile_store<OUT_KIND>(io, t, W, H, o);
 #pragma unroll
-            for (int c = 0; c < 3; c++) raw[c][1] = gload<u32x2>(src[c], t2.i1 >> 2);
+            for (int c = 0; c < 3; c++) raw[c][1] = gload<u32x2>(src[c], t2.q1);
             t_cur = t2;
         }
         mm6 mm;

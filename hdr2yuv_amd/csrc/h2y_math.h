@@ -351,6 +351,28 @@ H2Y_FN double pq_poly(uint32_t bits, const pq_recA &a, const pq_recB &b)
     v = __builtin_fma(v, ud, a.c1);
     return __builtin_fma(v, ud, a.c0);
 }
+H2Y_FN uint32_t umin3(uint32_t a, uint32_t b, uint32_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_min3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    const uint32_t m = a < b ? a : b;
+    return m < c ? m : c;
+#endif
+}
+H2Y_FN uint32_t umax3(uint32_t a, uint32_t b, uint32_t c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t r;
+    asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+#else
+    const uint32_t m = a > b ? a : b;
+    return m > c ? m : c;
+#endif
+}
 H2Y_FN uint32_t umin32(uint32_t a, uint32_t b)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -792,22 +814,40 @@ struct t1_sens {
     uint32_t cb_lo, cb_span;  /* chroma unsafe iff (hiword(fract(q)) - lo) >= span (wide) */
     uint32_t cr_lo, cr_span;
     uint32_t c_lo, c_span;    /* one window covering both (the wider of the two) */
+    uint32_t a_lo, a_hi;      /* YCbCr: one window for luma and both chromas, on hiword(fract()) of the three binary64
+                                 pre-truncation values: unsafe iff < a_lo or >= a_hi */
 };
 #define H2Y_GUARD_LO 0x3E100000u                  /* hiword(2^-30): the always-on guard of the reciprocal division */
 #define H2Y_GUARD_SPAN (0x3FEFFFFFu - 0x3E100000u) /* up to hiword(1 - 2^-21) */
+#define H2Y_GUARD_HI 0x3FEFFFFFu
 
+/* two-condition form: the pixel must be redone iff *ra | *rb (kept apart for the kernel: each is the
+ * lane mask of one compare, and ORing lane masks is scalar work) */
 template <int MODE>
-H2Y_FN bool pix_matrix_t1(const pix_params &pp, const t1_sens &sn, float G, float B, float R, bool vunc, uint32_t &Yo,
-                          uint32_t &Cbo, uint32_t &Cro)
+H2Y_FN void pix_matrix_t1(const pix_params &pp, const t1_sens &sn, float G, float B, float R, bool vunc, uint32_t &Yo,
+                          uint32_t &Cbo, uint32_t &Cro, bool *ra, bool *rb)
 {
     float ylike;
     double qb, qr;
     if (MODE == H2Y_MODE_YCBCR) {
-        double yd = ((pp.kr * (double)R + pp.kg * (double)G) + pp.kb * (double)B) + 0.5;
-        float tmpF = (float)yd;
-        ylike = tmpF;
+        const double yd = ((pp.kr * (double)R + pp.kg * (double)G) + pp.kb * (double)B) + 0.5;
+        const float tmpF = (float)yd;
         qb = __builtin_fma((double)(B - tmpF), pp.inv_dcb, 0.5);
         qr = __builtin_fma((double)(R - tmpF), pp.inv_dcr, 0.5);
+        Yo = (uint32_t)sat_i32_f32(tmpF); /* unclamped: the caller's pix_yuv_clamp() bounds it below maxCV anyway (yhi_s <= maxCV) */
+        Cbo = chroma_clamped(sat_i32_f64(qb), pp.half_m1, pp.maxCV);
+        Cro = chroma_clamped(sat_i32_f64(qr), pp.half_m1, pp.maxCV);
+        /* One test for the three values: the high words of their fractional parts against one window --
+         * with an unsure sample the wide one (one-ulp sensitivity of any of the three), without one the
+         * narrow one inside it (the guard of the reciprocal division; harmless for the luma, whose float
+         * is exact then).  The luma is judged by its binary64 sum: Y = trunc(RN_float(yd)), and the
+         * window's margin includes that rounding (t1_bounds).  NaN => high word above every window. */
+        const uint32_t fy = (uint32_t)(d2bits(fract_f64(yd)) >> 32);
+        const uint32_t fb = (uint32_t)(d2bits(fract_f64(qb)) >> 32), fr = (uint32_t)(d2bits(fract_f64(qr)) >> 32);
+        const uint32_t lo = vunc ? sn.a_lo : H2Y_GUARD_LO, hi = vunc ? sn.a_hi : H2Y_GUARD_HI;
+        *ra = umin3(fy, fb, fr) < lo;
+        *rb = umax3(fy, fb, fr) >= hi;
+        return;
     } else { /* H2Y_MODE_YDZDX */
         ylike = G;
         double hg = (double)(-G) * 0.5;
@@ -820,18 +860,18 @@ H2Y_FN bool pix_matrix_t1(const pix_params &pp, const t1_sens &sn, float G, floa
     Cro = chroma_clamped(sat_i32_f64(qr), pp.half_m1, pp.maxCV);
     const uint32_t fb = (uint32_t)(d2bits(fract_f64(qb)) >> 32), fr = (uint32_t)(d2bits(fract_f64(qr)) >> 32);
     const bool y_unsafe = !(__builtin_fabsf(fract_f32(ylike) - 0.5f) < sn.ty); /* NaN => unsafe */
-    bool guard;
-    if (MODE == H2Y_MODE_YCBCR) {
-        /* with an unsure sample the wide window (one-ulp sensitivity) applies, without one only the
-         * narrow window inside it (the guard of the reciprocal division); either chroma outside => redo */
-        const uint32_t lo = vunc ? sn.c_lo : H2Y_GUARD_LO, span = vunc ? sn.c_span : H2Y_GUARD_SPAN;
-        const uint32_t db = fb - lo, dr = fr - lo;
-        guard = (db > dr ? db : dr) >= span;
-    } else {
-        /* YDzDx has no division, so without an unsure sample its chroma needs no guard at all */
-        guard = vunc & (((fb - sn.cb_lo) >= sn.cb_span) | ((fr - sn.cr_lo) >= sn.cr_span));
-    }
-    return guard | (vunc & y_unsafe);
+    /* YDzDx has no division, so without an unsure sample its chroma needs no guard at all */
+    const bool guard = vunc & (((fb - sn.cb_lo) >= sn.cb_span) | ((fr - sn.cr_lo) >= sn.cr_span));
+    *ra = guard | (vunc & y_unsafe);
+    *rb = false;
+}
+template <int MODE>
+H2Y_FN bool pix_matrix_t1(const pix_params &pp, const t1_sens &sn, float G, float B, float R, bool vunc, uint32_t &Yo,
+                          uint32_t &Cbo, uint32_t &Cro)
+{
+    bool ra, rb;
+    pix_matrix_t1<MODE>(pp, sn, G, B, R, vunc, Yo, Cbo, Cro, &ra, &rb);
+    return ra | rb;
 }
 
 /* Host: how far a one-ulp change of each PQ value can move the pre-truncation
@@ -868,6 +908,10 @@ inline bool t1_bounds(const pix_params &pp, t1_sens *sn)
         const uint32_t hb = sn->cb_lo + sn->cb_span, hr = sn->cr_lo + sn->cr_span;
         sn->c_lo = sn->cb_lo > sn->cr_lo ? sn->cb_lo : sn->cr_lo; /* safe region = intersection of the two */
         sn->c_span = (hb < hr ? hb : hr) - sn->c_lo;
+        /* and with the luma's: fract(yd) in [Ey, 1 - Ey) */
+        const uint32_t y_lo = hiword_of(Ey) + 1, y_hi = hiword_of(1.0 - Ey);
+        sn->a_lo = sn->c_lo > y_lo ? sn->c_lo : y_lo;
+        sn->a_hi = (sn->c_lo + sn->c_span) < y_hi ? (sn->c_lo + sn->c_span) : y_hi;
     }
     /* ~3 % of pixels have an unsure sample; the share of pixels redone is ~0.03 * 2 (Ey + Ecb + Ecr):
      * 0.05 % at 12 bits (0.4 % of the eight-pixel tiles), 0.2 % at 14 and 0.8 % at 16 bits (tools/t1_check).
@@ -901,14 +945,18 @@ H2Y_FN uint32_t umed3(uint32_t v, uint32_t lo, uint32_t hi)
 }
 /* Clamping the unshifted value to [lo << s, (hi << s) | (2^s - 1)] and shifting afterwards gives the
  * same number as shifting first and clamping to [lo, hi]: one v_med3_u32 and one shift. */
+template <bool NOSHIFT = false> /* NOSHIFT: the caller knows down_shift == 0 (float input) */
 H2Y_FN uint32_t pix_yuv_clamp(const pix_params &pp, uint32_t v, bool chroma)
 {
-    return umed3(v, chroma ? pp.clo_s : pp.ylo_s, chroma ? pp.chi_s : pp.yhi_s) >> pp.down_shift;
+    const uint32_t c = umed3(v, chroma ? pp.clo_s : pp.ylo_s, chroma ? pp.chi_s : pp.yhi_s);
+    return NOSHIFT ? c : c >> pp.down_shift;
 }
 /* the 2x2 box: (a+b+c+d)/4 (convert.cpp:157-160, unsigned truncation), write_yuv's shift and clamp */
+template <bool NOSHIFT = false>
 H2Y_FN uint32_t pix_box_clamp(const pix_params &pp, uint32_t sum4)
 {
-    return umed3(sum4, pp.clo_b, pp.chi_b) >> (pp.down_shift + 2);
+    const uint32_t c = umed3(sum4, pp.clo_b, pp.chi_b);
+    return NOSHIFT ? c >> 2 : c >> (pp.down_shift + 2);
 }
 
 /* clamp to [0, maxCV] and truncate (convert.cpp:314-317, 372-374); t is never NaN (sums of finite samples) */

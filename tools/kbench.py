@@ -13,7 +13,7 @@ import hdr2yuv_amd as h
 from hdr2yuv_amd.synth import synth_frame
 
 
-def timeit(ctx, d, frames_in, label, steps=10, bytes_per_px=15.0):
+def timeit(ctx, d, frames_in, label, steps=int(os.environ.get("STEPS", "10")), bytes_per_px=15.0):
     F = len(frames_in)
     nb = h.frame_bytes(d)
     outs_t = [torch.empty(nb // 2, dtype=torch.int16, device="cuda") for _ in range(F)]

@@ -783,6 +783,9 @@ int h2y_batch_finish(h2y_ctx *ctx, int *n_redone)
     }
     ctx->last_ms = ms;
     ctx->last_launches = ctx->n_ev;
+#ifdef H2Y_BLOCK_TIMES
+    if (const char *e = getenv("H2Y_BLOCK_TIMES_FILE")) h2y_dump_block_times(e);
+#endif
     int redone = 0;
     const h2y_desc *d = &ctx->p_desc;
     t1_end_batch(ctx, d, ctx->h_fstats, ctx->p_n);

@@ -117,6 +117,9 @@ struct inverse_args {
     int shift, shift_right;
 };
 
+#ifdef H2Y_BLOCK_TIMES
+void h2y_dump_block_times(const char *path); /* timing experiments only */
+#endif
 int h2y_fused_threads(const fused_variant &v);
 const char *h2y_fused_name(const fused_variant &v);
 bool h2y_fused_grouped(const fused_variant &v); /* does the kernel honour fused_args.groups? */

@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <stdio.h>
 
 #include "h2y_math.h"
 #include "h2y_kernels.h"
@@ -827,9 +828,24 @@ __device__ __forceinline__ void redo_pass(const redo_ctx *rc, const pix_params *
 #endif
 }
 
+#ifdef H2Y_BLOCK_TIMES /* timing experiments only: when does each block start its first tile and finish its last? */
+__device__ unsigned long long g_block_times[2 * 1024];
+void h2y_dump_block_times(const char *path)
+{
+    static unsigned long long h[2 * 1024];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_block_times), sizeof h) != hipSuccess) return;
+    FILE *f = fopen(path, "w");
+    if (!f) return;
+    for (int i = 0; i < 1024; i++) fprintf(f, "%d %llu %llu\n", i, h[2 * i], h[2 * i + 1]);
+    fclose(f);
+}
+#endif
 template <int IN_KIND, int OUT_KIND, int MODE, int PIPE>
 __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
 {
+#ifdef H2Y_BLOCK_TIMES
+    if (threadIdx.x == 0) g_block_times[2 * blockIdx.x] = wall_clock64();
+#endif
     __shared__ pq_rec1 s_t1[H2Y_T1_NREC];
     __shared__ pq_recA s_t2[2 * H2Y_PQ_NREC]; /* A records, then B records */
     __shared__ uint32_t s_redo[H2Y_T1_THREADS / WAVE][H2Y_REDO_CAP];
@@ -931,15 +947,44 @@ if (PIPE == H2Y_PIPE_PQ_IDENT) {
                         mm.add2(2, rv[0], rv[1]); mm.add2(2, rv[2], rv[3]);
                     }
                     uint32_t Y[4], Cb[4], Cr[4];
+#ifndef H2Y_T1_AHEAD
+#define H2Y_T1_AHEAD 1 /* the three records of a pixel on their way before the first is used: -1.7 % */
+#endif
+#if H2Y_T1_AHEAD == 2
+                    pq_rec1 ng = pq_t1_fetch(norm1<PIPE>(pp, 0, gv[0]), s_t1), nb = pq_t1_fetch(norm1<PIPE>(pp, 1, bv[0]), s_t1),
+                            nr = pq_t1_fetch(norm1<PIPE>(pp, 2, rv[0]), s_t1);
+#endif
 #pragma unroll
                     for (int col = 0; col < 4; col++) {
+#ifdef H2Y_HALF_COMPUTE /* timing experiments only: how much of the time is arithmetic? */
+                        if (row == 1) { Y[col] = o.yp0[col >> 1] >> (16 * (col & 1)) & 0xFFFFu; Cb[col] = sb[col >> 1] >> 1; Cr[col] = sr[col >> 1] >> 1; continue; }
+#endif
                         const float Gn = norm1<PIPE>(pp, 0, gv[col]);
                         const float Bn = norm1<PIPE>(pp, 1, bv[col]);
                         const float Rn = norm1<PIPE>(pp, 2, rv[col]);
                         bool ug, ub, ur;
+#if H2Y_T1_AHEAD == 0
                         const float g = pix_scale(pq_t1(Gn, s_t1, &ug), pp.mulY, pp.addY);
                         const float b = pix_scale(pq_t1(Bn, s_t1, &ub), pp.mulC, pp.addC);
                         const float r = pix_scale(pq_t1(Rn, s_t1, &ur), pp.mulC, pp.addC);
+#elif H2Y_T1_AHEAD == 1
+                        const pq_rec1 cg = pq_t1_fetch(Gn, s_t1), cb = pq_t1_fetch(Bn, s_t1), cr = pq_t1_fetch(Rn, s_t1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        const float g = pix_scale(pq_t1_eval(Gn, cg, &ug), pp.mulY, pp.addY);
+                        const float b = pix_scale(pq_t1_eval(Bn, cb, &ub), pp.mulC, pp.addC);
+                        const float r = pix_scale(pq_t1_eval(Rn, cr, &ur), pp.mulC, pp.addC);
+#else
+                        const pq_rec1 cg = ng, cb = nb, cr = nr;
+                        if (col < 3) {
+                            ng = pq_t1_fetch(norm1<PIPE>(pp, 0, gv[col + 1]), s_t1);
+                            nb = pq_t1_fetch(norm1<PIPE>(pp, 1, bv[col + 1]), s_t1);
+                            nr = pq_t1_fetch(norm1<PIPE>(pp, 2, rv[col + 1]), s_t1);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        const float g = pix_scale(pq_t1_eval(Gn, cg, &ug), pp.mulY, pp.addY);
+                        const float b = pix_scale(pq_t1_eval(Bn, cb, &ub), pp.mulC, pp.addC);
+                        const float r = pix_scale(pq_t1_eval(Rn, cr, &ur), pp.mulC, pp.addC);
+#endif
                         bool ra, rb;
                         pix_matrix_t1<MODE>(pp, sn, g, b, r, ug | ub | ur, Y[col], Cb[col], Cr[col], &ra, &rb);
                         redo_m |= __builtin_amdgcn_ballot_w64(ra) | __builtin_amdgcn_ballot_w64(rb); /* a ballot of a compare is the compare's own result */
@@ -989,6 +1034,10 @@ if (PIPE == H2Y_PIPE_PQ_IDENT) {
         if (a.redo_count && lane == 0) a.redo_count[fw.slot(H2Y_T1_THREADS / WAVE)] = flagged_f;
     }
     if (n_redo) redo_pass<IN_KIND, OUT_KIND, MODE, PIPE>(&s_rc, &s_pp, s_t2, my_list, 0u, n_redo);
+#ifdef H2Y_BLOCK_TIMES
+    __syncthreads();
+    if (threadIdx.x == 0) g_block_times[2 * blockIdx.x + 1] = wall_clock64();
+#endif
     (void)lane;
 }
 

@@ -556,6 +556,37 @@ H2Y_FN uint32_t pq_t1_offset(float x)
 #endif
     return ((f2bits(c) >> H2Y_T1_LOW_BITS) << 4) - ((H2Y_T1_BASE - 1u) << 4);
 }
+/* the two halves of pq_t1(): the record's fetch, and the evaluation -- so that a kernel can have
+ * several records on their way from LDS before the first is used */
+H2Y_FN pq_rec1 pq_t1_fetch(float x, const pq_rec1 *__restrict__ T)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const __attribute__((address_space(3))) pq_rec1 *lds_rec;
+    const uint32_t tbase = (uint32_t)(uintptr_t)(lds_rec)T - ((H2Y_T1_BASE - 1u) << 4);
+    const uint32_t seg = f2bits(__builtin_amdgcn_fmed3f(x, bits2f(H2Y_T1_LO_SENTINEL_BITS), 2.0f)) >> H2Y_T1_LOW_BITS;
+    uint32_t addr;
+    asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(addr) : "v"(seg), "s"(tbase));
+    return *(lds_rec)(uintptr_t)addr;
+#else
+    return *reinterpret_cast<const pq_rec1 *>(reinterpret_cast<const char *>(T) + pq_t1_offset(x));
+#endif
+}
+H2Y_FN float pq_t1_eval(float x, const pq_rec1 &r, bool *unsure)
+{
+    float c0h, ws;
+    pq_t1_parts(f2bits(x), r, &c0h, &ws);
+    const float s = __builtin_fmaf(ws, 0x1p-25f, c0h);
+    const float es = __builtin_fmaf(s - c0h, -0x1p25f, ws);
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t tb;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(tb) : "v"(f2bits(s)), "s"(0x7F800000u), "v"(H2Y_T1_THR_MANT));
+    const float thr = bits2f(tb);
+#else
+    const float thr = bits2f((f2bits(s) & 0x7F800000u) | H2Y_T1_THR_MANT);
+#endif
+    *unsure = !(__builtin_fabsf(es) < thr);
+    return s;
+}
 H2Y_FN float pq_t1(float x, const pq_rec1 *__restrict__ T, bool *unsure)
 {
     const uint32_t bits = f2bits(x);

@@ -83,6 +83,18 @@ struct h2y_ctx {
      * The kernel counts the tiles it had to redo; when their share in a batch exceeds kT1DenseShare the next
      * kT1SkipBatches batches go to k_fused2 (the binary64 tier answers zero by itself), then the first tier is
      * tried again. */
+    /* Balancing across XCDs (frame_walk in h2y_kernels.hip): the loop-form kernels leave the mean run time of the blocks
+     * of each XCD; the shares of the next launch follow the speeds seen (balance_update()). */
+    unsigned long long *d_clock = nullptr;
+    size_t clock_cap = 0;
+    float *d_xcd = nullptr, *h_xcd = nullptr; /* [8] */
+    bool bal_pending = false;                 /* h_xcd will hold the times of a launch dealt with bal_used_* */
+    uint32_t bal_used_mask = 0xFFu;
+    double bal_used_extra = 0.0;              /* work of a fast block relative to a slow one, minus one, in that launch */
+    bool bal_have = false;
+    double bal_speed[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+    uint32_t bal_mask = 0xFFu;                /* the XCDs that get the second part */
+    double bal_rho = 1.0;                     /* how much more work a fast block gets than a slow one */
     int t1_skip = 0, t1_skip_len = 0;
     bool cur_skip_t1 = false;
     bool last_was_t1 = false;
@@ -355,6 +367,90 @@ int out_kind_of(const h2y_desc *d)
     return d->chroma_resampler_type == 0 ? H2Y_OUT_420BOX : H2Y_OUT_444TMP;
 }
 
+/* H2Y_BALANCE=off keeps the rounds unweighted; H2Y_BALANCE=<mask>,<rho> (e.g. 0x55,1.07) fixes the weights (tests, A/B timing) */
+int balance_env(uint32_t *mask, double *rho)
+{
+    int mode = 0; /* 0 adaptive, 1 off, 2 fixed; read at every launch (the tests change it) */
+    uint32_t m = 0xFFu;
+    double r = 1.0;
+    const char *e = getenv("H2Y_BALANCE");
+    if (e && !strcmp(e, "off")) mode = 1;
+    else if (e) {
+        char *end = nullptr;
+        const unsigned long mm = strtoul(e, &end, 0);
+        if (end && *end == ',' && (mm & 0xFFu) && (mm & 0xFFu) != 0xFFu) {
+            m = (uint32_t)(mm & 0xFFu);
+            r = atof(end + 1);
+            if (r > 1.0) mode = 2;
+        }
+    }
+    *mask = m;
+    *rho = r;
+    return mode;
+}
+
+/* the split of a frame's chunks for this launch: chunks [0, *chunks_a) round all blocks, the rest round the fast ones */
+void balance_for_launch(const h2y_ctx *ctx, uint32_t cpf, uint32_t *mask, uint32_t *chunks_a, double *extra)
+{
+    uint32_t m = ctx->bal_mask;
+    double rho = ctx->bal_rho;
+    uint32_t em;
+    double er;
+    const int mode = balance_env(&em, &er);
+    if (mode == 1) { m = 0xFFu; rho = 1.0; }
+    if (mode == 2) { m = em; rho = er; }
+    *mask = 0xFFu;
+    *chunks_a = cpf;
+    *extra = 0.0;
+    if (m == 0xFFu || !(rho > 1.0)) return;
+    const double fshare = (double)__builtin_popcount(m) / 8.0; /* Gf / G */
+    /* fast block: cpfA / G + cpfB / Gf = rho * cpfA / G  =>  cpfA = cpf / (1 + (rho - 1) * Gf / G) */
+    uint32_t ca = (uint32_t)((double)cpf / (1.0 + (rho - 1.0) * fshare) + 0.5);
+    if (ca > cpf) ca = cpf;
+    if (ca < 1) ca = 1;
+    if (ca == cpf) return;
+    *mask = m;
+    *chunks_a = ca;
+    *extra = ((double)(cpf - ca) / fshare) / (double)ca; /* the ratio actually dealt, minus one */
+}
+
+/* after a launch whose block clocks came back: speeds per XCD, and from them the next launch's shares */
+void balance_update(h2y_ctx *ctx)
+{
+    if (!ctx->bal_pending) return;
+    ctx->bal_pending = false;
+    double sp[8], mean = 0.0;
+    for (int x = 0; x < 8; x++) {
+        const double t = ctx->h_xcd[x];
+        if (!(t > 0.0)) return; /* grid smaller than a round of XCDs, or nothing measured */
+        const double w = ((ctx->bal_used_mask >> x) & 1u) && ctx->bal_used_mask != 0xFFu ? 1.0 + ctx->bal_used_extra : 1.0;
+        sp[x] = w / t;
+        mean += sp[x] / 8.0;
+    }
+    double lo = 1e30, hi = 0.0;
+    for (int x = 0; x < 8; x++) {
+        sp[x] /= mean;
+        ctx->bal_speed[x] = ctx->bal_have ? 0.5 * ctx->bal_speed[x] + 0.5 * sp[x] : sp[x];
+        lo = ctx->bal_speed[x] < lo ? ctx->bal_speed[x] : lo;
+        hi = ctx->bal_speed[x] > hi ? ctx->bal_speed[x] : hi;
+    }
+    ctx->bal_have = true;
+    ctx->bal_mask = 0xFFu;
+    ctx->bal_rho = 1.0;
+    if (hi < 1.01 * lo) return; /* level: one part */
+    const double thr = 0.5 * (hi + lo);
+    uint32_t m = 0;
+    double sf = 0.0, ss = 0.0;
+    int nf = 0;
+    for (int x = 0; x < 8; x++)
+        if (ctx->bal_speed[x] > thr) { m |= 1u << x; sf += ctx->bal_speed[x]; nf++; }
+        else ss += ctx->bal_speed[x];
+    if (nf == 0 || nf == 8) return;
+    ctx->bal_mask = m;
+    ctx->bal_rho = (sf / nf) / (ss / (8 - nf));
+    if (ctx->bal_rho > 1.5) ctx->bal_rho = 1.5;
+}
+
 /* launch fused (+FIR) over frames [0,n) whose frame_io entries are in h_frames */
 int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, const assumed_stats *d_assumed,
                const assumed_stats *known, bool check, int fstats_offset, bool time_it)
@@ -420,7 +516,29 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
             }
         }
         if (check) ctx->approx_min = approx;
+        /* XCD-aware rounds and their weights; the block clocks of timed launches feed balance_update() */
+        const bool xcd_layout = h2y_fused_grouped(var) && grid % (8 * groups) == 0;
+        uint32_t fast_mask = 0xFFu, chunks_a = g.chunks;
+        double extra = 0.0;
+        if (xcd_layout) balance_for_launch(ctx, g.chunks, &fast_mask, &chunks_a, &extra);
+        const bool clocks = xcd_layout && time_it;
+        if (clocks) {
+            const size_t need = (size_t)2 * grid * sizeof(unsigned long long);
+            if (ctx->clock_cap < need) {
+                rc = ensure(ctx, ctx->d_clock, ctx->clock_cap, need);
+                if (rc) return rc;
+                HIP_TRY(ctx, hipMemsetAsync(ctx->d_clock, 0, need, ctx->stream)); /* k_stats_final clears the finish entries from here on */
+            }
+            if (!ctx->d_xcd) {
+                HIP_TRY(ctx, hipMalloc((void **)&ctx->d_xcd, 8 * sizeof(float)));
+                HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_xcd, 8 * sizeof(float), hipHostMallocDefault));
+            }
+        }
         fused_args a;
+        a.xcd_layout = xcd_layout ? 1u : 0u;
+        a.fast_mask = fast_mask;
+        a.chunks_a = chunks_a;
+        a.block_clock = clocks ? ctx->d_clock : nullptr;
         a.redo_count = t1 ? ctx->d_redo : nullptr;
         a.low_flag = approx ? ctx->d_low : nullptr;
         a.frames = ctx->d_frames + ctx->slot_base + f0;
@@ -461,7 +579,16 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         fa.check = check ? 1 : 0;
         fa.assumed = d_assumed;
         fa.publish = nullptr;
+        fa.block_clock = clocks ? ctx->d_clock : nullptr;
+        fa.grid = grid;
+        fa.xcd_time = ctx->d_xcd;
         HIP_TRY(ctx, h2y_launch_stats_final(nf, ctx->stream, fa));
+        if (clocks) {
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->h_xcd, ctx->d_xcd, 8 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+            ctx->bal_pending = true;
+            ctx->bal_used_mask = fast_mask;
+            ctx->bal_used_extra = extra;
+        }
         if (out_kind == H2Y_OUT_444TMP) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev_fused[half], ctx->stream));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->fir_stream, ctx->ev_fused[half], 0));
@@ -537,6 +664,9 @@ int run_stats(h2y_ctx *ctx, const h2y_desc *d, const void *const in[3], int slot
     fa.check = 0;
     fa.assumed = nullptr;
     fa.publish = publish;
+    fa.block_clock = nullptr;
+    fa.grid = 0;
+    fa.xcd_time = nullptr;
     HIP_TRY(ctx, h2y_launch_stats_final(1, ctx->stream, fa));
     return 0;
 }
@@ -678,6 +808,9 @@ void h2y_ctx_destroy(h2y_ctx *ctx)
     (void)hipFree(ctx->d_partial);
     (void)hipFree(ctx->d_redo);
     (void)hipFree(ctx->d_low);
+    (void)hipFree(ctx->d_clock);
+    (void)hipFree(ctx->d_xcd);
+    if (ctx->h_xcd) (void)hipHostFree(ctx->h_xcd);
     (void)hipFree(ctx->d_fstats);
     (void)hipHostFree(ctx->h_fstats);
     (void)hipFree(ctx->d_assumed);
@@ -789,6 +922,7 @@ int h2y_batch_finish(h2y_ctx *ctx, int *n_redone)
     int redone = 0;
     const h2y_desc *d = &ctx->p_desc;
     t1_end_batch(ctx, d, ctx->h_fstats, ctx->p_n);
+    balance_update(ctx);
     if (ctx->p_check) {
         for (int f = 0; f < ctx->p_n; f++) {
             if (!ctx->h_fstats[f].mismatch) continue;
@@ -1158,6 +1292,10 @@ int h2y_matrix_convert(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3
     a.tiles_per_frame = g.tiles;
     a.chunks_per_frame = g.chunks;
     a.groups = 1;
+    a.xcd_layout = 0;
+    a.fast_mask = 0xFFu;
+    a.chunks_a = g.chunks;
+    a.block_clock = nullptr;
     a.table = ctx->d_table;
     a.lut16 = ctx->d_lut16;
     a.table1 = ctx->d_table1;

@@ -55,6 +55,10 @@ struct fused_args {
     uint32_t chunks_per_frame;
     uint32_t groups;          /* k_fused2 / k_fused_t1 / k_fused_lut16: the grid works as this many groups of gridDim.x / groups
                                  blocks, group g on frames g, g + groups, ... (1: every block on every frame); divides gridDim.x */
+    uint32_t xcd_layout;      /* 1: gridDim.x is a multiple of 8 * groups and groups are made of whole rounds of the eight XCDs */
+    uint32_t fast_mask;       /* xcd_layout: the XCDs (bit = blockIdx.x % 8) whose blocks take the second part of every frame */
+    uint32_t chunks_a;        /* xcd_layout: chunks [0, chunks_a) of a frame go round all blocks, the rest round the fast ones */
+    unsigned long long *block_clock; /* [gridDim.x][2]: start, finish (wall_clock64) of each block, or NULL; finish entries zero at launch */
     const void *table;        /* pq_recA[NREC] then pq_recB[NREC] */
     const float *lut16;       /* k_fused_lut16: PQ of every half in [0,2) */
     const void *table1;       /* k_fused_t1: pq_rec1[H2Y_T1_NREC] */
@@ -95,6 +99,9 @@ struct final_args {
     int check;                     /* compare against *assumed, set frame_stats.mismatch */
     const assumed_stats *assumed;  /* may be NULL when check == 0 */
     assumed_stats *publish;        /* not NULL: frame 0's floor/ceiling are written here */
+    unsigned long long *block_clock; /* not NULL: fused_args.block_clock of the launch just finished ... */
+    int grid;                        /* ... its grid ... */
+    float *xcd_time;                 /* ... and where block 0 leaves the mean run time (us) of the blocks of each XCD [8]; clears the finish entries */
 };
 
 struct fir_args {

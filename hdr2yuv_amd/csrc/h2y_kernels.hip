@@ -586,56 +586,122 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
 /*
  * Which frames a block of the loop-form kernels works on, and which chunks of them.
  *
- * A wave pays a fixed price per frame (min/max reduction over the wave, frame descriptors, the first
- * tile's latency: ~230 vector instructions, a third of a tile's), and with every block on every frame
- * a 4K frame is only four tiles per lane.  So the grid works as a.groups groups of G = gridDim.x /
- * groups blocks (block b: group b % groups, number b / groups in it); group g takes frames g,
- * g + groups, ...: the same price, groups times as many tiles per lane and frame.  Within a group,
- * chunk c of the group's n-th frame belongs to block (n * chunks_per_frame + c) % G, so the blocks of
- * a group stay level across frames (gbase = n * chunks_per_frame % G, kept incrementally).
+ * Frame groups.  A wave pays a fixed price per frame (min/max reduction over the wave, frame
+ * descriptors, the first tile's latency: ~230 vector instructions, a third of a tile's), and with every
+ * block on every frame a 4K frame is only four tiles per lane.  So the grid works as a.groups groups of
+ * G = gridDim.x / groups blocks; group g takes frames g, g + groups, ...: the same price, groups times
+ * as many tiles per lane and frame.  With a.xcd_layout (gridDim.x a multiple of 8 * groups) a group is
+ * made of whole rounds of the eight XCDs (block b runs on XCD b % 8): group (b / 8) % groups, number
+ * ((b / 8) / groups) * 8 + b % 8 in it.
+ *
+ * Weighted rounds.  The XCDs of a card are not equally fast on this kernel (measured: the odd ones
+ * 7 % slower; tools/blocktimes.py), and a static round-robin ends when the slowest block ends.  A
+ * frame's chunks are therefore dealt in two parts: chunks [0, chunks_a) go round ALL blocks of the
+ * group, chunks [chunks_a, chunks_per_frame) round the blocks on the FAST XCDs (a.fast_mask) only.  The
+ * host sets the split from the finish times of the previous launch (balance_update() in h2y_api.hip).
+ * Both rounds rotate from frame to frame (chunk c of the group's n-th frame: block (n chunks_a + c) % G
+ * in part A, fast block (n chunks_b + c - chunks_a) % Gf in part B), so blocks stay level across frames.
  */
 struct frame_walk {
-    uint32_t G, NG, bi, cpf_mod, gbase;
+    uint32_t G, NG, bi;           /* blocks per group, groups, this block's number in its group */
+    uint32_t Gf, fi;              /* fast blocks per group, this block's number among them */
+    bool fast;
+    uint32_t cpf, cpfA;           /* chunks per frame, chunks of part A */
+    uint32_t modA, modB, gbA, gbB;
     int f;
+    uint32_t kA, kB, kA_n, kB_n;  /* this block's first chunk of part A / B in this frame and in the group's next one; >= the part's end: none */
+
+    __device__ __forceinline__ uint32_t wrapA(uint32_t x) const { return x >= G ? x - G : x; }   /* x < 2 G */
+    __device__ __forceinline__ uint32_t wrapB(uint32_t x) const { return x >= Gf ? x - Gf : x; } /* x < 2 Gf */
+    __device__ __forceinline__ void set_firsts()
+    {
+        kA = wrapA(bi + G - gbA);
+        kB = fast ? cpfA + wrapB(fi + Gf - gbB) : cpf;
+        kA_n = wrapA(bi + G - wrapA(gbA + modA));
+        kB_n = fast ? cpfA + wrapB(fi + Gf - wrapB(gbB + modB)) : cpf;
+    }
     __device__ __forceinline__ void init(const fused_args &a)
     {
+        const uint32_t b = blockIdx.x;
         NG = a.groups;
         G = gridDim.x / NG;
-        bi = blockIdx.x / NG;
-        f = (int)(blockIdx.x % NG);
-        cpf_mod = a.chunks_per_frame % G;
-        gbase = 0;
+        cpf = a.chunks_per_frame;
+        if (a.xcd_layout) {
+            const uint32_t xcd = b & 7u, nf8 = (uint32_t)__popc(a.fast_mask & 0xFFu);
+            f = (int)((b >> 3) % NG);
+            bi = ((b >> 3) / NG) * 8u + xcd;
+            Gf = (G >> 3) * nf8;
+            fast = ((a.fast_mask >> xcd) & 1u) != 0;
+            fi = (bi >> 3) * nf8 + (uint32_t)__popc(a.fast_mask & ((1u << xcd) - 1u));
+            cpfA = a.chunks_a;
+        } else {
+            f = (int)(b % NG);
+            bi = b / NG;
+            Gf = G;
+            fast = false;
+            fi = 0;
+            cpfA = cpf; /* one part */
+        }
+        modA = cpfA % G;
+        modB = (cpf - cpfA) % Gf;
+        gbA = gbB = 0;
+        set_firsts();
     }
     __device__ __forceinline__ bool has_next(const fused_args &a) const { return f + (int)NG < a.n_frames; }
-    __device__ __forceinline__ uint32_t wrap(uint32_t x) const { return x >= G ? x - G : x; } /* x < 2 G */
-    __device__ __forceinline__ uint32_t first_k() const { return wrap(bi + G - gbase); }
-    __device__ __forceinline__ uint32_t k_next_frame() const { return wrap(bi + G - wrap(gbase + cpf_mod)); }
     __device__ __forceinline__ void advance()
     {
-        gbase = wrap(gbase + cpf_mod);
+        gbA = wrapA(gbA + modA);
+        gbB = wrapB(gbB + modB);
         f += (int)NG;
+        set_firsts();
+    }
+    /* this block's first chunk of the current frame */
+    __device__ __forceinline__ bool first(uint32_t &k, bool &inB) const
+    {
+        const bool hasA = kA < cpfA;
+        k = hasA ? kA : kB;
+        inB = !hasA;
+        return hasA || kB < cpf;
+    }
+    /* the chunk after k: 1 = in the same frame, 2 = in the group's next frame, 0 = none (k2 = k) */
+    __device__ __forceinline__ int succ(const fused_args &a, uint32_t k, bool inB, uint32_t &k2, bool &inB2) const
+    {
+        const uint32_t ks = k + (inB ? Gf : G);
+        const bool same1 = ks < (inB ? cpf : cpfA);
+        const bool toB = !same1 && !inB && kB < cpf;
+        const bool nA = kA_n < cpfA, nB = kB_n < cpf;
+        const bool next = !same1 && !toB && has_next(a) && (nA || nB);
+        k2 = same1 ? ks : toB ? kB : next ? (nA ? kA_n : kB_n) : k;
+        inB2 = same1 ? inB : toB ? true : next ? !nA : inB;
+        return (same1 || toB) ? 1 : next ? 2 : 0;
     }
     /* this wave's slot in the per-frame arrays: [frame][block of the group][wave] */
     __device__ __forceinline__ size_t slot(uint32_t waves) const { return ((size_t)f * G + bi) * waves + threadIdx.x / WAVE; }
 };
 
 /* The branch-free loop forms (k_fused2, k_fused_t1, k_fused_lut16) ask for the next tile while they
- * work on the current one.  Where does this block go after chunk k of frame f: chunk k + G of the same
- * frame, else its first chunk of the next frame (k_next_frame), else nowhere -- then the current tile is
- * simply asked for again (the request is unconditional).  Returns the next tile's position and which
- * frame's planes to read; *have says whether the data requested is the tile the block meets next. */
+ * work on the current one: the tile of chunk k2 = frame_walk::succ(k) -- in the same frame, in the
+ * group's next frame, or nowhere: then the current tile is simply asked for again (the request is
+ * unconditional).  Returns the next tile's position and which frame's planes to read; *have says whether
+ * the data requested is the tile the block meets next. */
 template <int THREADS>
-__device__ __forceinline__ tile_pos next_tile(const fused_args &a, const frame_walk &fw, uint32_t k, uint32_t k_next_frame, const frame_io &io,
-                                              const frame_io &io_next, const void *(&src)[3], bool *have)
+__device__ __forceinline__ tile_pos next_tile(const fused_args &a, int kind, uint32_t k2, const frame_io &io, const frame_io &io_next,
+                                              const void *(&src)[3], bool *have)
 {
-    uint32_t k2 = k + fw.G;
-    const bool same = k2 < a.chunks_per_frame;
-    if (!same) k2 = k_next_frame;
-    *have = same || (fw.has_next(a) && k2 < a.chunks_per_frame);
-    if (!*have) k2 = k;
+    *have = kind != 0;
 #pragma unroll
-    for (int c = 0; c < 3; c++) src[c] = (!same && *have) ? io_next.in[c] : io.in[c];
+    for (int c = 0; c < 3; c++) src[c] = kind == 2 ? io_next.in[c] : io.in[c];
     return tile_locate(umin32(k2 * THREADS + threadIdx.x, a.tiles_per_frame - 1u), a.width, a.height, a.wq, a.wq_magic);
+}
+
+/* finish time of the block, for the host's balancing: the latest of its waves */
+__device__ __forceinline__ void block_clock_start(const fused_args &a)
+{
+    if (a.block_clock && threadIdx.x == 0) a.block_clock[2 * blockIdx.x] = wall_clock64();
+}
+__device__ __forceinline__ void block_clock_end(const fused_args &a)
+{
+    if (a.block_clock && (threadIdx.x & (WAVE - 1)) == 0) atomicMax(&a.block_clock[2 * blockIdx.x + 1], (unsigned long long)wall_clock64());
 }
 
 /*
@@ -668,6 +734,7 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
     const pix_params pp = with_assumed(a.pp, a.assumed);
     __syncthreads();
 
+    block_clock_start(a);
     const uint32_t W = a.width, H = a.height;
     tile_in v;         /* the tile being worked on; refilled row by row with the next one */
     tile_pos t_cur;    /* and where it is */
@@ -676,25 +743,28 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
     frame_walk fw;
     for (fw.init(a); fw.f < a.n_frames; fw.advance()) {
         const int f = fw.f;
-        const uint32_t G = fw.G;
         const frame_io io = uniform_io(a.frames + f);
         const frame_io io_next = uniform_io(a.frames + (fw.has_next(a) ? f + (int)fw.NG : f));
         mm6 mm;
         mm.reset();
-        const uint32_t k_next_frame = fw.k_next_frame();
-        uint32_t k = fw.first_k();
-        if (!have && k < a.chunks_per_frame) {
+        uint32_t k;
+        bool inB;
+        bool more = fw.first(k, inB);
+        if (!have && more) {
             t_cur = tile_locate(umin32(k * H2Y_FUSED_THREADS + threadIdx.x, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
             tile_load<IN_KIND>(io, t_cur, v);
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 asm volatile("" ::"v"(v.g0[j]), "v"(v.b0[j]), "v"(v.r0[j]), "v"(v.g1[j]), "v"(v.b1[j]), "v"(v.r1[j]));
         }
-        for (; k < a.chunks_per_frame; k += G) {
+        while (more) {
             tile_pos t = t_cur;
             t.row1 = true;
             const void *src[3];
-            const tile_pos t2 = next_tile<H2Y_FUSED_THREADS>(a, fw, k, k_next_frame, io, io_next, src, &have);
+            uint32_t k2;
+            bool inB2;
+            const int kind = fw.succ(a, k, inB, k2, inB2);
+            const tile_pos t2 = next_tile<H2Y_FUSED_THREADS>(a, kind, k2, io, io_next, src, &have);
 
             tile_out o;
             uint32_t sb[2], sr[2];
@@ -731,9 +801,13 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
             IN::load4q(src[1], t2.q1, v.b1);
             IN::load4q(src[2], t2.q1, v.r1);
             t_cur = t2;
+            more = kind == 1;
+            k = k2;
+            inB = inB2;
         }
         wave_store_mm(mm, a.partial + fw.slot(H2Y_FUSED_THREADS / WAVE) * 6);
     }
+    block_clock_end(a);
 }
 
 /*
@@ -873,6 +947,7 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
     }
     __syncthreads();
 
+    block_clock_start(a);
     const uint32_t W = a.width, H = a.height;
     const uint32_t lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
     uint32_t *const my_list = s_redo[wave];
@@ -897,16 +972,16 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
     frame_walk fw;
     for (fw.init(a); fw.f < a.n_frames; fw.advance()) {
         const int f = fw.f;
-        const uint32_t G = fw.G;
         const frame_io io = uniform_io(a.frames + f);
         const frame_io io_next = uniform_io(a.frames + (fw.has_next(a) ? f + (int)fw.NG : f)); /* for the prefetch across the frame boundary */
         mm6 mm;
         mm.reset();
-        const uint32_t k_next_frame = fw.k_next_frame();
         const uint32_t id_base = (uint32_t)f * a.tiles_per_frame;
         uint32_t flagged_f = 0; /* tiles of this frame this wave sent to the list (the host steers by their share) */
-        uint32_t k = fw.first_k();
-        while (k < a.chunks_per_frame) {
+        uint32_t k;
+        bool inB;
+        bool more = fw.first(k, inB);
+        while (more) {
             if (!have) { /* nothing on its way (first tile of the launch, or a block that skipped frames) */
                 t_cur = tile_locate(umin32(k * H2Y_T1_THREADS + threadIdx.x, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
                 tile_load<IN_KIND>(io, t_cur, v);
@@ -916,12 +991,15 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 asm volatile("" ::"v"(v.g0[j]), "v"(v.b0[j]), "v"(v.r0[j]), "v"(v.g1[j]), "v"(v.b1[j]), "v"(v.r1[j]));
-            for (; k < a.chunks_per_frame && n_redo < WAVE; k += G) {
+            do {
                 const uint32_t tt = k * H2Y_T1_THREADS + threadIdx.x;
                 tile_pos t = t_cur; /* located one iteration ago, as the prefetch target */
                 t.row1 = true;
                 const void *src[3];
-                const tile_pos t2 = next_tile<H2Y_T1_THREADS>(a, fw, k, k_next_frame, io, io_next, src, &have);
+                uint32_t k2;
+                bool inB2;
+                const int kind = fw.succ(a, k, inB, k2, inB2);
+                const tile_pos t2 = next_tile<H2Y_T1_THREADS>(a, kind, k2, io, io_next, src, &have);
 
                 tile_out o;
                 uint32_t sb[2], sr[2]; /* 2x2 box: chroma sums of the two blocks */
@@ -1021,7 +1099,10 @@ if (PIPE == H2Y_PIPE_PQ_IDENT) {
                     n_redo += (uint32_t)__popcll(m);
                     flagged_f += (uint32_t)__popcll(m);
                 }
-            }
+                more = kind == 1;
+                k = k2;
+                inB = inB2;
+            } while (more && n_redo < WAVE);
             if (n_redo >= WAVE) { /* 64 tiles to redo: one per lane */
                 n_redo -= WAVE;
 #ifndef H2Y_SKIP_REDO /* timing experiments only: what do the passes cost? */
@@ -1034,6 +1115,7 @@ if (PIPE == H2Y_PIPE_PQ_IDENT) {
         if (a.redo_count && lane == 0) a.redo_count[fw.slot(H2Y_T1_THREADS / WAVE)] = flagged_f;
     }
     if (n_redo) redo_pass<IN_KIND, OUT_KIND, MODE, PIPE>(&s_rc, &s_pp, s_t2, my_list, 0u, n_redo);
+    block_clock_end(a);
 #ifdef H2Y_BLOCK_TIMES
     __syncthreads();
     if (threadIdx.x == 0) g_block_times[2 * blockIdx.x + 1] = wall_clock64();
@@ -1081,6 +1163,7 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
     if (threadIdx.x == 0) s_pp = pp;
     __syncthreads();
 
+    block_clock_start(a);
     const uint32_t W = a.width, H = a.height;
     /* the loop form of k_fused_t1: row-wise tiles, rolling prefetch (8-byte loads: four halves), one
      * basic block of memory operations; even height (the host sends odd heights to k_fused) */
@@ -1090,7 +1173,6 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
     frame_walk fw;
     for (fw.init(a); fw.f < a.n_frames; fw.advance()) {
         const int f = fw.f;
-        const uint32_t G = fw.G;
         const frame_io io = uniform_io(a.frames + f);
         const frame_io io_next = uniform_io(a.frames + (fw.has_next(a) ? f + (int)fw.NG : f));
         /* packed-half accumulators: {min, max} x plane, two halves per dword */
@@ -1100,9 +1182,10 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
             mn[c] = 0x7C007C00u; /* +inf stands in for FLT_MAX (common.cpp:118): no finite or infinite sample is "< FLT_MAX" unless it is finite */
             mx[c] = 0x00000000u; /* +0: FLT_MIN (1.2e-38) is below the smallest half; (int) of either is 0 */
         }
-        const uint32_t k_next_frame = fw.k_next_frame();
-        uint32_t k = fw.first_k();
-        if (!have && k < a.chunks_per_frame) {
+        uint32_t k;
+        bool inB;
+        bool more = fw.first(k, inB);
+        if (!have && more) {
             t_cur = tile_locate(umin32(k * H2Y_FUSED_THREADS + threadIdx.x, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
 #pragma unroll
             for (int c = 0; c < 3; c++) {
@@ -1113,11 +1196,14 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
             for (int c = 0; c < 3; c++)
                 asm volatile("" ::"v"(raw[c][0].x), "v"(raw[c][0].y), "v"(raw[c][1].x), "v"(raw[c][1].y));
         }
-        for (; k < a.chunks_per_frame; k += G) {
+        while (more) {
             tile_pos t = t_cur;
             t.row1 = true;
             const void *src[3];
-            const tile_pos t2 = next_tile<H2Y_FUSED_THREADS>(a, fw, k, k_next_frame, io, io_next, src, &have);
+            uint32_t k2;
+            bool inB2;
+            const int kind = fw.succ(a, k, inB, k2, inB2);
+            const tile_pos t2 = next_tile<H2Y_FUSED_THREADS>(a, kind, k2, io, io_next, src, &have);
             tile_out o;
             uint32_t sb[2], sr[2];
 #pragma unroll
@@ -1156,6 +1242,9 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
 #pragma unroll
             for (int c = 0; c < 3; c++) raw[c][1] = gload<u32x2>(src[c], t2.q1);
             t_cur = t2;
+            more = kind == 1;
+            k = k2;
+            inB = inB2;
         }
         mm6 mm;
 #pragma unroll
@@ -1169,6 +1258,7 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
         }
         wave_store_mm(mm, a.partial + fw.slot(H2Y_FUSED_THREADS / WAVE) * 6);
     }
+    block_clock_end(a);
 }
 
 /* PQ10000_r() of every half in [0, 2) through the exact tiers; table records read from HBM */
@@ -1330,6 +1420,23 @@ __global__ __launch_bounds__(256) void k_stats_final(final_args a)
             a.low_flag[f] = 0u; /* ready for the next launch */
         }
         out->mismatch = bad;
+    }
+    /* the launch's block clocks, per XCD (block b ran on XCD b % 8): the host balances the next launch by them */
+    if (a.block_clock && f == 0) {
+        __shared__ unsigned long long s_t0, s_sum[8];
+        __shared__ int s_n[8];
+        if (threadIdx.x == 0) s_t0 = ~0ull;
+        if (threadIdx.x < 8) { s_sum[threadIdx.x] = 0ull; s_n[threadIdx.x] = 0; }
+        __syncthreads();
+        for (int b = threadIdx.x; b < a.grid; b += blockDim.x) atomicMin(&s_t0, a.block_clock[2 * b]);
+        __syncthreads();
+        for (int b = threadIdx.x; b < a.grid; b += blockDim.x) {
+            atomicAdd(&s_sum[b & 7], a.block_clock[2 * b + 1] - s_t0);
+            atomicAdd(&s_n[b & 7], 1);
+            a.block_clock[2 * b + 1] = 0ull; /* ready for the next launch's atomicMax */
+        }
+        __syncthreads();
+        if (threadIdx.x < 8) a.xcd_time[threadIdx.x] = s_n[threadIdx.x] ? (float)((double)s_sum[threadIdx.x] / s_n[threadIdx.x] * 0.01) : 0.f; /* 100 MHz ticks -> us */
     }
 }
 

@@ -736,3 +736,45 @@ def test_frame_groups(oracle, kind, n, w, hh):
                 assert np.array_equal(got, want[f]), f"round {rnd} frame {f}: {np.count_nonzero(got != want[f])} samples differ"
     finally:
         fresh.close()
+
+
+@pytest.mark.parametrize("balance", ["0x55,1.07", "0xAA,1.4", "0x01,1.5", "0xFE,1.2", "off"])
+def test_weighted_rounds(oracle, balance):
+    """The loop-form kernels deal a frame's chunks in two parts -- all blocks, then the blocks on the fast
+    XCDs only (frame_walk) -- with weights the host derives from block finish times.  Here the weights are
+    fixed through H2Y_BALANCE, extreme ones included; frames large enough for the full grid (so that the
+    XCD layout applies) and batch lengths with 1, 2 and 8 frame groups; every chunk must be done exactly once."""
+    import os
+    import torch
+
+    rng = np.random.default_rng(515)
+    w, hh = 2048, 1024  # 262 144 tiles: 256 chunks of 1024 (k_fused_t1), 512 of 512 (k_fused2)
+    old = os.environ.get("H2Y_BALANCE")
+    os.environ["H2Y_BALANCE"] = balance
+    fresh = h.Context(0)
+    try:
+        for (n, depth, mat, chroma) in ((3, 12, h.MATRIX_BT2020NC, h.CHROMA_420), (8, 12, h.MATRIX_BT2020NC, h.CHROMA_420),
+                                        (2, 16, h.MATRIX_YDZDX, h.CHROMA_444)):
+            d = h.make_desc(w, hh, dst_depth=depth, dst_matrix=mat, chroma=chroma, resampler=0)
+            host = []
+            for k in range(n):
+                planes = [rng.uniform(0.0, 1.0, w * hh).astype(np.float32) for _ in range(3)]
+                for p in planes:
+                    p[k] = 1.0
+                host.append(planes)
+            dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in host]
+            od = _to_oracle_desc(d)
+            want = [oracle.convert_frame(od, fr) for fr in host]
+            for rnd in range(2):
+                dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda") for _ in host]
+                torch.cuda.synchronize()
+                fresh.convert_batch(d, dev_in, dev_out)
+                for f in range(n):
+                    got = dev_out[f].cpu().numpy().view(np.uint16)
+                    assert np.array_equal(got, want[f]), f"{balance} n={n} round {rnd} frame {f}: {np.count_nonzero(got != want[f])} samples differ"
+    finally:
+        fresh.close()
+        if old is None:
+            os.environ.pop("H2Y_BALANCE", None)
+        else:
+            os.environ["H2Y_BALANCE"] = old

@@ -1423,20 +1423,23 @@ __global__ __launch_bounds__(256) void k_stats_final(final_args a)
     }
     /* the launch's block clocks, per XCD (block b ran on XCD b % 8): the host balances the next launch by them */
     if (a.block_clock && f == 0) {
-        __shared__ unsigned long long s_t0, s_sum[8];
-        __shared__ int s_n[8];
-        if (threadIdx.x == 0) s_t0 = ~0ull;
-        if (threadIdx.x < 8) { s_sum[threadIdx.x] = 0ull; s_n[threadIdx.x] = 0; }
+        /* 32-bit ticks relative to block 0's start (the starts lie within microseconds, a launch lasts
+         * milliseconds: 100 MHz ticks fit easily): native LDS atomics */
+        __shared__ int s_t0;
+        __shared__ uint32_t s_sum[8], s_n[8];
+        const unsigned long long ref = a.block_clock[0];
+        if (threadIdx.x == 0) s_t0 = 0;
+        if (threadIdx.x < 8) { s_sum[threadIdx.x] = 0u; s_n[threadIdx.x] = 0u; }
         __syncthreads();
-        for (int b = threadIdx.x; b < a.grid; b += blockDim.x) atomicMin(&s_t0, a.block_clock[2 * b]);
+        for (int b = threadIdx.x; b < a.grid; b += blockDim.x) atomicMin(&s_t0, (int)(long long)(a.block_clock[2 * b] - ref));
         __syncthreads();
         for (int b = threadIdx.x; b < a.grid; b += blockDim.x) {
-            atomicAdd(&s_sum[b & 7], a.block_clock[2 * b + 1] - s_t0);
-            atomicAdd(&s_n[b & 7], 1);
+            atomicAdd(&s_sum[b & 7], (uint32_t)((long long)(a.block_clock[2 * b + 1] - ref) - s_t0));
+            atomicAdd(&s_n[b & 7], 1u);
             a.block_clock[2 * b + 1] = 0ull; /* ready for the next launch's atomicMax */
         }
         __syncthreads();
-        if (threadIdx.x < 8) a.xcd_time[threadIdx.x] = s_n[threadIdx.x] ? (float)((double)s_sum[threadIdx.x] / s_n[threadIdx.x] * 0.01) : 0.f; /* 100 MHz ticks -> us */
+        if (threadIdx.x < 8) a.xcd_time[threadIdx.x] = s_n[threadIdx.x] ? (float)s_sum[threadIdx.x] / (float)s_n[threadIdx.x] * 0.01f : 0.f; /* 100 MHz ticks -> us */
     }
 }
 

@@ -325,11 +325,29 @@ __device__ __forceinline__ uint32_t udiv_magic(uint32_t n, uint32_t d, uint32_t 
     return q;
 }
 
+/* N 16-byte records from global memory to LDS: every load of a thread is issued before the first is
+ * stored (as a plain loop the copy is one memory round trip per iteration -- ten of them, 10-15 us, at the
+ * head of every launch of the first-tier kernel) */
+template <int THREADS, int N> __device__ __forceinline__ void stage16(const void *src, void *dst)
+{
+    constexpr int IT = (N + THREADS - 1) / THREADS;
+    const uint4 *g = reinterpret_cast<const uint4 *>(src);
+    uint4 *l = reinterpret_cast<uint4 *>(dst);
+    uint4 r[IT];
+#pragma unroll
+    for (int j = 0; j < IT; j++) {
+        const int i = threadIdx.x + j * THREADS;
+        if (j < IT - 1 || i < N) r[j] = g[i];
+    }
+#pragma unroll
+    for (int j = 0; j < IT; j++) {
+        const int i = threadIdx.x + j * THREADS;
+        if (j < IT - 1 || i < N) l[i] = r[j];
+    }
+}
 template <int THREADS> __device__ __forceinline__ void stage_table(const void *table, pq_recA *s_tab)
 {
-    const uint4 *g = reinterpret_cast<const uint4 *>(table);
-    uint4 *l = reinterpret_cast<uint4 *>(s_tab);
-    for (int i = threadIdx.x; i < 2 * H2Y_PQ_NREC; i += THREADS) l[i] = g[i];
+    stage16<THREADS, 2 * H2Y_PQ_NREC>(table, s_tab);
 }
 
 /* ---- the thread tile: 4 columns x 2 rows ------------------------------- */
@@ -926,9 +944,7 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
     __shared__ pix_params s_pp;
     __shared__ redo_ctx s_rc;
     {
-        const uint4 *g = reinterpret_cast<const uint4 *>(a.table1);
-        uint4 *l = reinterpret_cast<uint4 *>(s_t1);
-        for (int i = threadIdx.x; i < H2Y_T1_NREC; i += H2Y_T1_THREADS) l[i] = g[i];
+        stage16<H2Y_T1_THREADS, H2Y_T1_NREC>(a.table1, s_t1);
         stage_table<H2Y_T1_THREADS>(a.table, s_t2);
     }
     const pix_params pp = with_assumed(a.pp, a.assumed);
@@ -1155,9 +1171,7 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
     __shared__ float s_lut[H2Y_LUT16_N];
     __shared__ pix_params s_pp;
     {
-        const uint4 *g = reinterpret_cast<const uint4 *>(a.lut16);
-        uint4 *l = reinterpret_cast<uint4 *>(s_lut);
-        for (int i = threadIdx.x; i < H2Y_LUT16_N / 4; i += H2Y_FUSED_THREADS) l[i] = g[i];
+        stage16<H2Y_FUSED_THREADS, H2Y_LUT16_N / 4>(a.lut16, s_lut);
     }
     const pix_params pp = with_assumed(a.pp, a.assumed);
     if (threadIdx.x == 0) s_pp = pp;

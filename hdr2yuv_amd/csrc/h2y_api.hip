@@ -267,11 +267,11 @@ struct geom {
     bool narrow;
     uint32_t wq, wq_magic, tiles, chunks;
 };
-geom make_geom(const h2y_desc *d, int threads)
+geom make_geom(const h2y_desc *d, int threads, int cols = 4 /* columns of a thread tile (8: k_fused_lut16 on wide-aligned pictures) */)
 {
     geom g;
     g.narrow = (d->width % 4) != 0;
-    g.wq = g.narrow ? (uint32_t)d->width : (uint32_t)d->width / 4;
+    g.wq = g.narrow ? (uint32_t)d->width : (uint32_t)d->width / (uint32_t)cols;
     g.wq_magic = (uint32_t)(0x100000000ull / g.wq);
     if (g.wq == 1) g.wq_magic = 0xFFFFFFFFu;
     g.tiles = g.wq * (uint32_t)((d->height + 1) / 2);
@@ -464,7 +464,17 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
     if ((var.pipe == 4 || var.pipe == 5) && (uint64_t)n * make_geom(d, h2y_fused_threads(var)).tiles >= 0xFFFFFFFFull) var.pipe -= 3;
     if ((var.pipe == 4 || var.pipe == 5) && ctx->cur_skip_t1) var.pipe -= 3; /* dense zeros lately: binary64 tier for now */
     ctx->last_was_t1 = var.pipe == 4 || var.pipe == 5;
-    const geom g = make_geom(d, h2y_fused_threads(var));
+    if (var.pipe == 3 && d->width % 8 == 0) { /* half input through the table: 8-column tiles when every plane allows 16-byte accesses */
+        bool ok = true;
+        const char *e = getenv("H2Y_COLS8"); /* =0: the general 4-column form (A/B timing) */
+        if (e && e[0] == '0') ok = false;
+        for (int i = 0; i < n && ok; i++) {
+            for (int c = 0; c < 3; c++) ok = ok && (reinterpret_cast<uintptr_t>(frames[i].in[c]) & 15u) == 0;
+            ok = ok && (reinterpret_cast<uintptr_t>(frames[i].out) & 15u) == 0;
+        }
+        var.cols8 = ok;
+    }
+    const geom g = make_geom(d, h2y_fused_threads(var), var.cols8 ? 8 : 4);
     const size_t npix = (size_t)d->width * d->height;
     const int step = out_kind == H2Y_OUT_444TMP ? kFirSubBatch : n;
     if (out_kind == H2Y_OUT_444TMP) {

@@ -80,6 +80,7 @@ struct fused_variant {
                       6 equal transfers, no PQ at all (k_fused2) */
     bool narrow;   /* width % 4 != 0: scalar-load variant */
     bool even_h;   /* height % 2 == 0: the branch-free loop forms (k_fused2, k_fused_t1) apply */
+    bool cols8 = false; /* k_fused_lut16 only: 8-column thread tiles (width % 8 == 0, all planes 16-byte aligned); wq and tiles count those */
 };
 
 struct stats_args {

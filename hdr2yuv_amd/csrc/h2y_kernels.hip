@@ -1196,9 +1196,45 @@ __device__ __forceinline__ uint32_t pk_max_h(uint32_t a, uint32_t b)
 }
 __device__ __forceinline__ float half_bits_to_float(uint32_t h) { return (float)__builtin_bit_cast(_Float16, (uint16_t)h); }
 
-template <int OUT_KIND, int MODE>
+/* COLS = 8: the thread tile is 8 columns x 2 rows (width % 8 == 0, planes 16-byte aligned): halves are two
+ * bytes, so only then are the accesses the 16 bytes per lane the memory pipeline likes best (loads and luma
+ * stores; 8 bytes for the 4:2:0 chroma) -- the same registers per thread as a 4-column tile of floats.
+ * a.wq = width / COLS, a.tiles_per_frame accordingly; COLS = 4 is the general form. */
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <int COLS> struct lut16_raw;
+template <> struct lut16_raw<4> { typedef u32x2 type; };
+template <> struct lut16_raw<8> { typedef u32x4 type; };
+/* two 4-column halves of an 8-column tile, stored together */
+template <int OUT_KIND>
+__device__ __forceinline__ void tile_store8(const frame_io &io, const tile_pos &t, uint32_t W, uint32_t H, const tile_out &a, const tile_out &b)
+{
+    const uint32_t npix = W * H;
+    gstore_nt<u32x4>(io.out, t.q0, u32x4{a.yp0[0], a.yp0[1], b.yp0[0], b.yp0[1]});
+    gstore_nt<u32x4>(io.out, t.q1, u32x4{a.yp1[0], a.yp1[1], b.yp1[0], b.yp1[1]});
+    if (OUT_KIND == H2Y_OUT_420BOX) {
+        /* four chroma samples per tile: sample index 4 tt in each plane, i.e. 8-byte unit tt */
+        const uint32_t ncb = (W >> 1) * (H >> 1);
+        gstore_nt<u32x2>(io.out, (npix >> 2) + t.tt, u32x2{a.cb_box, b.cb_box});
+        gstore_nt<u32x2>(io.out, ((npix + ncb) >> 2) + t.tt, u32x2{a.cr_box, b.cr_box});
+    } else if (OUT_KIND == H2Y_OUT_444) {
+        uint16_t *Cbp = io.out + npix, *Crp = io.out + 2 * (size_t)npix;
+        gstore_nt<u32x4>(Cbp, t.q0, u32x4{a.cbp0[0], a.cbp0[1], b.cbp0[0], b.cbp0[1]});
+        gstore_nt<u32x4>(Crp, t.q0, u32x4{a.crp0[0], a.crp0[1], b.crp0[0], b.crp0[1]});
+        gstore_nt<u32x4>(Cbp, t.q1, u32x4{a.cbp1[0], a.cbp1[1], b.cbp1[0], b.cbp1[1]});
+        gstore_nt<u32x4>(Crp, t.q1, u32x4{a.crp1[0], a.crp1[1], b.crp1[0], b.crp1[1]});
+    } else { /* scratch planes: k_fir420 reads them next */
+        gstore<u32x4>(io.tmp_cb, t.q0, u32x4{a.cbp0[0], a.cbp0[1], b.cbp0[0], b.cbp0[1]});
+        gstore<u32x4>(io.tmp_cr, t.q0, u32x4{a.crp0[0], a.crp0[1], b.crp0[0], b.crp0[1]});
+        gstore<u32x4>(io.tmp_cb, t.q1, u32x4{a.cbp1[0], a.cbp1[1], b.cbp1[0], b.cbp1[1]});
+        gstore<u32x4>(io.tmp_cr, t.q1, u32x4{a.crp1[0], a.crp1[1], b.crp1[0], b.crp1[1]});
+    }
+}
+
+template <int OUT_KIND, int MODE, int COLS>
 __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused_lut16(fused_args a)
 {
+    typedef typename lut16_raw<COLS>::type RV;
+    constexpr int NH = COLS / 4; /* 4-column halves per tile */
     __shared__ float s_lut[H2Y_LUT16_N];
     __shared__ pix_params s_pp;
     {
@@ -1210,9 +1246,9 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
 
     block_clock_start(a);
     const uint32_t W = a.width, H = a.height;
-    /* the loop form of k_fused_t1: row-wise tiles, rolling prefetch (8-byte loads: four halves), one
-     * basic block of memory operations; even height (the host sends odd heights to k_fused) */
-    u32x2 raw[3][2];   /* the tile being worked on, raw halves: [plane][row], four samples each */
+    /* the loop form of k_fused_t1: row-wise tiles, rolling prefetch, one basic block of memory
+     * operations; even height (the host sends odd heights to k_fused) */
+    RV raw[3][2];   /* the tile being worked on, raw halves: [plane][row], COLS samples each */
     tile_pos t_cur;
     bool have = false;
     frame_walk fw;
@@ -1234,12 +1270,13 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
             t_cur = tile_locate(umin32(k * H2Y_FUSED_THREADS + threadIdx.x, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
 #pragma unroll
             for (int c = 0; c < 3; c++) {
-                raw[c][0] = gload_nt<u32x2>(io.in[c], t_cur.q0);
-                raw[c][1] = gload_nt<u32x2>(io.in[c], t_cur.q1);
+                raw[c][0] = gload_nt<RV>(io.in[c], t_cur.q0);
+                raw[c][1] = gload_nt<RV>(io.in[c], t_cur.q1);
             }
 #pragma unroll
             for (int c = 0; c < 3; c++)
-                asm volatile("" ::"v"(raw[c][0].x), "v"(raw[c][0].y), "v"(raw[c][1].x), "v"(raw[c][1].y));
+#pragma unroll
+                for (int w = 0; w < COLS / 2; w++) asm volatile("" ::"v"(raw[c][0][w]), "v"(raw[c][1][w]));
         }
         while (more) {
             tile_pos t = t_cur;
@@ -1249,43 +1286,49 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
             bool inB2;
             const int kind = fw.succ(a, k, inB, k2, inB2);
             const tile_pos t2 = next_tile<H2Y_FUSED_THREADS>(a, kind, k2, io, io_next, src, &have);
-            tile_out o;
-            uint32_t sb[2], sr[2];
+            tile_out o[NH];
+            uint32_t sb[NH][2], sr[NH][2];
 #pragma unroll
             for (int row = 0; row < 2; row++) {
 #pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    mn[c] = pk_min_h(pk_min_h(mn[c], raw[c][row].x), raw[c][row].y);
-                    mx[c] = pk_max_h(pk_max_h(mx[c], raw[c][row].x), raw[c][row].y);
-                }
-                uint32_t Y[4], Cb[4], Cr[4];
+                for (int c = 0; c < 3; c++)
 #pragma unroll
-                for (int col = 0; col < 4; col++) {
-                    const uint32_t wg = col & 2 ? raw[0][row].y : raw[0][row].x;
-                    const uint32_t wb = col & 2 ? raw[1][row].y : raw[1][row].x;
-                    const uint32_t wr = col & 2 ? raw[2][row].y : raw[2][row].x;
-                    const uint32_t hg = col & 1 ? wg >> 16 : wg & 0xFFFFu, hb = col & 1 ? wb >> 16 : wb & 0xFFFFu, hr = col & 1 ? wr >> 16 : wr & 0xFFFFu;
-                    const float g = pix_scale(s_lut[hg & (H2Y_LUT16_N - 1)], pp.mulY, pp.addY);
-                    const float b = pix_scale(s_lut[hb & (H2Y_LUT16_N - 1)], pp.mulC, pp.addC);
-                    const float r = pix_scale(s_lut[hr & (H2Y_LUT16_N - 1)], pp.mulC, pp.addC);
-                    bool um;
-                    pix_matrix<MODE, false>(pp, g, b, r, Y[col], Cb[col], Cr[col], &um);
-                    const bool outside = ((hg | hb | hr) & ~(uint32_t)(H2Y_LUT16_N - 1)) != 0; /* negative, >= 2.0, inf, NaN */
-                    if (__builtin_expect(outside | um, 0)) {
-                        const ycc c = pixel_careful<MODE>(&s_pp, half_bits_to_float(hg), half_bits_to_float(hb), half_bits_to_float(hr));
-                        Y[col] = c.y; Cb[col] = c.cb; Cr[col] = c.cr;
+                    for (int w = 0; w < COLS / 2; w++) {
+                        mn[c] = pk_min_h(mn[c], raw[c][row][w]);
+                        mx[c] = pk_max_h(mx[c], raw[c][row][w]);
                     }
+#pragma unroll
+                for (int hf = 0; hf < NH; hf++) {
+                    uint32_t Y[4], Cb[4], Cr[4];
+#pragma unroll
+                    for (int col = 0; col < 4; col++) {
+                        const uint32_t wg = raw[0][row][2 * hf + (col >> 1)];
+                        const uint32_t wb = raw[1][row][2 * hf + (col >> 1)];
+                        const uint32_t wr = raw[2][row][2 * hf + (col >> 1)];
+                        const uint32_t hg = col & 1 ? wg >> 16 : wg & 0xFFFFu, hb = col & 1 ? wb >> 16 : wb & 0xFFFFu, hr = col & 1 ? wr >> 16 : wr & 0xFFFFu;
+                        const float g = pix_scale(s_lut[hg & (H2Y_LUT16_N - 1)], pp.mulY, pp.addY);
+                        const float b = pix_scale(s_lut[hb & (H2Y_LUT16_N - 1)], pp.mulC, pp.addC);
+                        const float r = pix_scale(s_lut[hr & (H2Y_LUT16_N - 1)], pp.mulC, pp.addC);
+                        bool um;
+                        pix_matrix<MODE, false>(pp, g, b, r, Y[col], Cb[col], Cr[col], &um);
+                        const bool outside = ((hg | hb | hr) & ~(uint32_t)(H2Y_LUT16_N - 1)) != 0; /* negative, >= 2.0, inf, NaN */
+                        if (__builtin_expect(outside | um, 0)) {
+                            const ycc c = pixel_careful<MODE>(&s_pp, half_bits_to_float(hg), half_bits_to_float(hb), half_bits_to_float(hr));
+                            Y[col] = c.y; Cb[col] = c.cb; Cr[col] = c.cr;
+                        }
+                    }
+                    row_pack<OUT_KIND, true>(pp, row, Y, Cb, Cr, o[hf], sb[hf], sr[hf]);
                 }
-                row_pack<OUT_KIND, true>(pp, row, Y, Cb, Cr, o, sb, sr);
                 if (row == 0) {
 #pragma unroll
-                    for (int c = 0; c < 3; c++) raw[c][0] = gload_nt<u32x2>(src[c], t2.q0);
+                    for (int c = 0; c < 3; c++) raw[c][0] = gload_nt<RV>(src[c], t2.q0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            tile_store<OUT_KIND>(io, t, W, H, o);
+            if (COLS == 8) tile_store8<OUT_KIND>(io, t, W, H, o[0], o[NH - 1]);
+            else tile_store<OUT_KIND>(io, t, W, H, o[0]);
 #pragma unroll
-            for (int c = 0; c < 3; c++) raw[c][1] = gload_nt<u32x2>(src[c], t2.q1);
+            for (int c = 0; c < 3; c++) raw[c][1] = gload_nt<RV>(src[c], t2.q1);
             t_cur = t2;
             more = kind == 1;
             k = k2;
@@ -1725,9 +1768,10 @@ template <int IN_KIND> static fused_fn pick_out(const fused_variant &v)
     default: return pick_mode<IN_KIND, H2Y_OUT_444TMP>(v.mode, v.pipe, v.even_h);
     }
 }
-template <int OUT_KIND> static fused_fn pick_lut_mode(int mode)
+template <int OUT_KIND> static fused_fn pick_lut_mode(int mode, bool cols8)
 {
-    return mode == H2Y_MODE_YCBCR ? k_fused_lut16<OUT_KIND, H2Y_MODE_YCBCR> : k_fused_lut16<OUT_KIND, H2Y_MODE_YDZDX>;
+    if (cols8) return mode == H2Y_MODE_YCBCR ? k_fused_lut16<OUT_KIND, H2Y_MODE_YCBCR, 8> : k_fused_lut16<OUT_KIND, H2Y_MODE_YDZDX, 8>;
+    return mode == H2Y_MODE_YCBCR ? k_fused_lut16<OUT_KIND, H2Y_MODE_YCBCR, 4> : k_fused_lut16<OUT_KIND, H2Y_MODE_YDZDX, 4>;
 }
 template <int IN_KIND, int OUT_KIND> static fused_fn pick_t1_mode(int mode, int pipe)
 {
@@ -1763,9 +1807,9 @@ static fused_fn pick_fused(const fused_variant &v)
         return v.in_kind == H2Y_IN_F16 ? pick_t1_out<H2Y_IN_F16>(v.out_kind, v.mode, v.pipe) : pick_t1_out<H2Y_IN_F32>(v.out_kind, v.mode, v.pipe);
     if (v.pipe == 3) {
         switch (v.out_kind) {
-        case H2Y_OUT_420BOX: return pick_lut_mode<H2Y_OUT_420BOX>(v.mode);
-        case H2Y_OUT_444: return pick_lut_mode<H2Y_OUT_444>(v.mode);
-        default: return pick_lut_mode<H2Y_OUT_444TMP>(v.mode);
+        case H2Y_OUT_420BOX: return pick_lut_mode<H2Y_OUT_420BOX>(v.mode, v.cols8);
+        case H2Y_OUT_444: return pick_lut_mode<H2Y_OUT_444>(v.mode, v.cols8);
+        default: return pick_lut_mode<H2Y_OUT_444TMP>(v.mode, v.cols8);
         }
     }
     switch (v.in_kind) {

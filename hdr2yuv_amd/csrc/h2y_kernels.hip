@@ -31,6 +31,7 @@
 
 #include "h2y_math.h"
 #include "h2y_kernels.h"
+#include "h2y_walk.h"
 
 using namespace h2y;
 
@@ -632,101 +633,17 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
     }
 }
 
-/*
- * Which frames a block of the loop-form kernels works on, and which chunks of them.
- *
- * Frame groups.  A wave pays a fixed price per frame (min/max reduction over the wave, frame
- * descriptors, the first tile's latency: ~230 vector instructions, a third of a tile's), and with every
- * block on every frame a 4K frame is only four tiles per lane.  So the grid works as a.groups groups of
- * G = gridDim.x / groups blocks; group g takes frames g, g + groups, ...: the same price, groups times
- * as many tiles per lane and frame.  With a.xcd_layout (gridDim.x a multiple of 8 * groups) a group is
- * made of whole rounds of the eight XCDs (block b runs on XCD b % 8): group (b / 8) % groups, number
- * ((b / 8) / groups) * 8 + b % 8 in it.
- *
- * Weighted rounds.  The XCDs of a card are not equally fast on this kernel (measured: the odd ones
- * 7 % slower; tools/blocktimes.py), and a static round-robin ends when the slowest block ends.  A
- * frame's chunks are therefore dealt in two parts: chunks [0, chunks_a) go round ALL blocks of the
- * group, chunks [chunks_a, chunks_per_frame) round the blocks on the FAST XCDs (a.fast_mask) only.  The
- * host sets the split from the finish times of the previous launch (balance_update() in h2y_api.hip).
- * Both rounds rotate from frame to frame (chunk c of the group's n-th frame: block (n chunks_a + c) % G
- * in part A, fast block (n chunks_b + c - chunks_a) % Gf in part B), so blocks stay level across frames.
- */
-struct frame_walk {
-    uint32_t G, NG, bi;           /* blocks per group, groups, this block's number in its group */
-    uint32_t Gf, fi;              /* fast blocks per group, this block's number among them */
-    bool fast;
-    uint32_t cpf, cpfA;           /* chunks per frame, chunks of part A */
-    uint32_t modA, modB, gbA, gbB;
-    int f;
-    uint32_t kA, kB, kA_n, kB_n;  /* this block's first chunk of part A / B in this frame and in the group's next one; >= the part's end: none */
-
-    __device__ __forceinline__ uint32_t wrapA(uint32_t x) const { return x >= G ? x - G : x; }   /* x < 2 G */
-    __device__ __forceinline__ uint32_t wrapB(uint32_t x) const { return x >= Gf ? x - Gf : x; } /* x < 2 Gf */
-    __device__ __forceinline__ void set_firsts()
-    {
-        kA = wrapA(bi + G - gbA);
-        kB = fast ? cpfA + wrapB(fi + Gf - gbB) : cpf;
-        kA_n = wrapA(bi + G - wrapA(gbA + modA));
-        kB_n = fast ? cpfA + wrapB(fi + Gf - wrapB(gbB + modB)) : cpf;
-    }
-    __device__ __forceinline__ void init(const fused_args &a)
-    {
-        const uint32_t b = blockIdx.x;
-        NG = a.groups;
-        G = gridDim.x / NG;
-        cpf = a.chunks_per_frame;
-        if (a.xcd_layout) {
-            const uint32_t xcd = b & 7u, nf8 = (uint32_t)__popc(a.fast_mask & 0xFFu);
-            f = (int)((b >> 3) % NG);
-            bi = ((b >> 3) / NG) * 8u + xcd;
-            Gf = (G >> 3) * nf8;
-            fast = ((a.fast_mask >> xcd) & 1u) != 0;
-            fi = (bi >> 3) * nf8 + (uint32_t)__popc(a.fast_mask & ((1u << xcd) - 1u));
-            cpfA = a.chunks_a;
-        } else {
-            f = (int)(b % NG);
-            bi = b / NG;
-            Gf = G;
-            fast = false;
-            fi = 0;
-            cpfA = cpf; /* one part */
-        }
-        modA = cpfA % G;
-        modB = (cpf - cpfA) % Gf;
-        gbA = gbB = 0;
-        set_firsts();
-    }
-    __device__ __forceinline__ bool has_next(const fused_args &a) const { return f + (int)NG < a.n_frames; }
-    __device__ __forceinline__ void advance()
-    {
-        gbA = wrapA(gbA + modA);
-        gbB = wrapB(gbB + modB);
-        f += (int)NG;
-        set_firsts();
-    }
-    /* this block's first chunk of the current frame */
-    __device__ __forceinline__ bool first(uint32_t &k, bool &inB) const
-    {
-        const bool hasA = kA < cpfA;
-        k = hasA ? kA : kB;
-        inB = !hasA;
-        return hasA || kB < cpf;
-    }
-    /* the chunk after k: 1 = in the same frame, 2 = in the group's next frame, 0 = none (k2 = k) */
-    __device__ __forceinline__ int succ(const fused_args &a, uint32_t k, bool inB, uint32_t &k2, bool &inB2) const
-    {
-        const uint32_t ks = k + (inB ? Gf : G);
-        const bool same1 = ks < (inB ? cpf : cpfA);
-        const bool toB = !same1 && !inB && kB < cpf;
-        const bool nA = kA_n < cpfA, nB = kB_n < cpf;
-        const bool next = !same1 && !toB && has_next(a) && (nA || nB);
-        k2 = same1 ? ks : toB ? kB : next ? (nA ? kA_n : kB_n) : k;
-        inB2 = same1 ? inB : toB ? true : next ? !nA : inB;
-        return (same1 || toB) ? 1 : next ? 2 : 0;
-    }
-    /* this wave's slot in the per-frame arrays: [frame][block of the group][wave] */
-    __device__ __forceinline__ size_t slot(uint32_t waves) const { return ((size_t)f * G + bi) * waves + threadIdx.x / WAVE; }
-};
+/* frame_walk (h2y_walk.h): which frames a block works on and which chunks of them -- frame groups, XCD-aware
+ * layout, weighted rounds.  Glue to the launch arguments: */
+__device__ __forceinline__ void walk_init(frame_walk &fw, const fused_args &a)
+{
+    walk_args wa;
+    wa.groups = a.groups; wa.xcd_layout = a.xcd_layout; wa.fast_mask = a.fast_mask; wa.chunks_a = a.chunks_a;
+    wa.chunks_per_frame = a.chunks_per_frame; wa.n_frames = a.n_frames;
+    fw.init(wa, blockIdx.x, gridDim.x);
+}
+/* this wave's slot in the per-frame arrays: [frame][block of the group][wave] */
+__device__ __forceinline__ size_t walk_slot(const frame_walk &fw, uint32_t waves) { return fw.slot() * waves + threadIdx.x / WAVE; }
 
 /* The branch-free loop forms (k_fused2, k_fused_t1, k_fused_lut16) ask for the next tile while they
  * work on the current one: the tile of chunk k2 = frame_walk::succ(k) -- in the same frame, in the
@@ -790,10 +707,10 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
     bool have = false; /* v holds the tile this block meets next (uniform) */
     typedef in_traits<IN_KIND> IN;
     frame_walk fw;
-    for (fw.init(a); fw.f < a.n_frames; fw.advance()) {
+    for (walk_init(fw, a); fw.f < a.n_frames; fw.advance()) {
         const int f = fw.f;
         const frame_io io = uniform_io(a.frames + f);
-        const frame_io io_next = uniform_io(a.frames + (fw.has_next(a) ? f + (int)fw.NG : f));
+        const frame_io io_next = uniform_io(a.frames + (fw.has_next() ? f + (int)fw.NG : f));
         mm6 mm;
         mm.reset();
         uint32_t k;
@@ -812,7 +729,7 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
             const void *src[3];
             uint32_t k2;
             bool inB2;
-            const int kind = fw.succ(a, k, inB, k2, inB2);
+            const int kind = fw.succ(k, inB, k2, inB2);
             const tile_pos t2 = next_tile<H2Y_FUSED_THREADS>(a, kind, k2, io, io_next, src, &have);
 
             tile_out o;
@@ -854,7 +771,7 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
             k = k2;
             inB = inB2;
         }
-        wave_store_mm(mm, a.partial + fw.slot(H2Y_FUSED_THREADS / WAVE) * 6);
+        wave_store_mm(mm, a.partial + walk_slot(fw, H2Y_FUSED_THREADS / WAVE) * 6);
     }
     block_clock_end(a);
 }
@@ -1017,10 +934,10 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
     bool have = false; /* v holds the tile this block meets next (uniform) */
     typedef in_traits<IN_KIND> IN;
     frame_walk fw;
-    for (fw.init(a); fw.f < a.n_frames; fw.advance()) {
+    for (walk_init(fw, a); fw.f < a.n_frames; fw.advance()) {
         const int f = fw.f;
         const frame_io io = uniform_io(a.frames + f);
-        const frame_io io_next = uniform_io(a.frames + (fw.has_next(a) ? f + (int)fw.NG : f)); /* for the prefetch across the frame boundary */
+        const frame_io io_next = uniform_io(a.frames + (fw.has_next() ? f + (int)fw.NG : f)); /* for the prefetch across the frame boundary */
         mm6 mm;
         mm.reset();
         const uint32_t id_base = (uint32_t)f * a.tiles_per_frame;
@@ -1045,7 +962,7 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
                 const void *src[3];
                 uint32_t k2;
                 bool inB2;
-                const int kind = fw.succ(a, k, inB, k2, inB2);
+                const int kind = fw.succ(k, inB, k2, inB2);
                 const tile_pos t2 = next_tile<H2Y_T1_THREADS>(a, kind, k2, io, io_next, src, &have);
 
                 tile_out o;
@@ -1158,8 +1075,8 @@ if (PIPE == H2Y_PIPE_PQ_IDENT) {
 #endif
             }
         }
-        wave_store_mm(mm, a.partial + fw.slot(H2Y_T1_THREADS / WAVE) * 6);
-        if (a.redo_count && lane == 0) a.redo_count[fw.slot(H2Y_T1_THREADS / WAVE)] = flagged_f;
+        wave_store_mm(mm, a.partial + walk_slot(fw, H2Y_T1_THREADS / WAVE) * 6);
+        if (a.redo_count && lane == 0) a.redo_count[walk_slot(fw, H2Y_T1_THREADS / WAVE)] = flagged_f;
     }
     if (n_redo) redo_pass<IN_KIND, OUT_KIND, MODE, PIPE>(&s_rc, &s_pp, s_t2, my_list, 0u, n_redo);
     block_clock_end(a);
@@ -1252,10 +1169,10 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
     tile_pos t_cur;
     bool have = false;
     frame_walk fw;
-    for (fw.init(a); fw.f < a.n_frames; fw.advance()) {
+    for (walk_init(fw, a); fw.f < a.n_frames; fw.advance()) {
         const int f = fw.f;
         const frame_io io = uniform_io(a.frames + f);
-        const frame_io io_next = uniform_io(a.frames + (fw.has_next(a) ? f + (int)fw.NG : f));
+        const frame_io io_next = uniform_io(a.frames + (fw.has_next() ? f + (int)fw.NG : f));
         /* packed-half accumulators: {min, max} x plane, two halves per dword */
         uint32_t mn[3], mx[3];
 #pragma unroll
@@ -1284,7 +1201,7 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
             const void *src[3];
             uint32_t k2;
             bool inB2;
-            const int kind = fw.succ(a, k, inB, k2, inB2);
+            const int kind = fw.succ(k, inB, k2, inB2);
             const tile_pos t2 = next_tile<H2Y_FUSED_THREADS>(a, kind, k2, io, io_next, src, &have);
             tile_out o[NH];
             uint32_t sb[NH][2], sr[NH][2];
@@ -1344,7 +1261,7 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
             mm.lo[c] = mm.lo[c] > 65504.0f ? 3.402823466e+38f : mm.lo[c]; /* still +inf: no sample was below FLT_MAX */
             mm.hi[c] = mm.hi[c] <= 0.0f ? 1.175494351e-38f : mm.hi[c];
         }
-        wave_store_mm(mm, a.partial + fw.slot(H2Y_FUSED_THREADS / WAVE) * 6);
+        wave_store_mm(mm, a.partial + walk_slot(fw, H2Y_FUSED_THREADS / WAVE) * 6);
     }
     block_clock_end(a);
 }

@@ -778,3 +778,56 @@ def test_weighted_rounds(oracle, balance):
             os.environ.pop("H2Y_BALANCE", None)
         else:
             os.environ["H2Y_BALANCE"] = old
+
+
+def test_mixed_sequence_on_one_context(oracle):
+    """One context, a sequence of batches that differ in everything the context keeps state about: sample
+    type, size (full grid / small grid), bit depth, resampler, statistics (hint right / wrong), black frames
+    (tier steering), batch length (frame groups, weighted rounds with clocks fed back between launches)."""
+    import torch
+
+    rng = np.random.default_rng(20261004)
+    fresh = h.Context(0)
+
+    def run(d, host, conv):
+        dev_in = [[conv(p) for p in fr] for fr in host]
+        dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda") for _ in host]
+        torch.cuda.synchronize()
+        fresh.convert_batch(d, dev_in, dev_out)
+        od = _to_oracle_desc(d)
+        for f, fr in enumerate(host):
+            got = dev_out[f].cpu().numpy().view(np.uint16)
+            want = oracle.convert_frame(od, fr)
+            assert np.array_equal(got, want), f"{d.width}x{d.height} frame {f}: {np.count_nonzero(got != want)} samples differ"
+
+    f32 = lambda p: torch.from_numpy(np.ascontiguousarray(p)).cuda()
+    i16 = lambda p: torch.from_numpy(np.ascontiguousarray(p).view(np.int16)).cuda()
+
+    def frames_f32(n, w, hh, top=1.0, black=()):
+        out = []
+        for k in range(n):
+            planes = [rng.uniform(0.0, 1.0, w * hh).astype(np.float32) for _ in range(3)]
+            for p in planes:
+                p[k] = top
+                if k in black:
+                    p[:] = 0.0
+            out.append(planes)
+        return out
+
+    try:
+        big = (2048, 512)  # 131 072 tiles: the full grid of 256 blocks, XCD layout
+        for step in range(2):
+            run(h.make_desc(*big, dst_depth=12, dst_matrix=h.MATRIX_BT2020NC, resampler=0), frames_f32(8, *big), f32)
+            run(h.make_desc(256, 64, dst_depth=10, dst_matrix=h.MATRIX_BT709, resampler=1), frames_f32(5, 256, 64), f32)
+            hf = [[p.astype(np.float16).view(np.uint16) for p in fr] for fr in frames_f32(4, 1024, 256)]
+            run(h.make_desc(1024, 256, sample=h.SAMPLE_F16, dst_depth=10, dst_matrix=h.MATRIX_BT2020NC, resampler=0), hf, i16)
+            u16 = [[rng.integers(0, 65536, 512 * 128, dtype=np.uint16) for _ in range(3)] for _ in range(6)]
+            run(h.make_desc(512, 128, sample=h.SAMPLE_U16, src_depth=16, dst_depth=10, dst_matrix=h.MATRIX_BT2020NC, resampler=0,
+                            src_transfer=16, dst_transfer=16), u16, i16)
+            run(h.make_desc(*big, dst_depth=12, dst_matrix=h.MATRIX_BT2020NC, resampler=0), frames_f32(8, *big, top=2.5), f32)  # hint wrong
+            run(h.make_desc(*big, dst_depth=12, dst_matrix=h.MATRIX_BT2020NC, resampler=0), frames_f32(4, *big, black=(0, 1, 2, 3)), f32)
+            run(h.make_desc(*big, dst_depth=16, dst_matrix=h.MATRIX_YDZDX, chroma=h.CHROMA_444), frames_f32(2, *big), f32)
+            run(h.make_desc(132, 36, dst_depth=12, dst_matrix=h.MATRIX_BT2020NC, resampler=0), frames_f32(3, 132, 36), f32)
+            run(h.make_desc(*big, dst_depth=12, dst_matrix=h.MATRIX_BT2020NC, resampler=1), frames_f32(3, *big), f32)
+    finally:
+        fresh.close()

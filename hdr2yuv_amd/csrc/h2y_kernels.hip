@@ -1223,9 +1223,14 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
                         const uint32_t wb = raw[1][row][2 * hf + (col >> 1)];
                         const uint32_t wr = raw[2][row][2 * hf + (col >> 1)];
                         const uint32_t hg = col & 1 ? wg >> 16 : wg & 0xFFFFu, hb = col & 1 ? wb >> 16 : wb & 0xFFFFu, hr = col & 1 ? wr >> 16 : wr & 0xFFFFu;
-                        const float g = pix_scale(s_lut[hg & (H2Y_LUT16_N - 1)], pp.mulY, pp.addY);
-                        const float b = pix_scale(s_lut[hb & (H2Y_LUT16_N - 1)], pp.mulC, pp.addC);
-                        const float r = pix_scale(s_lut[hr & (H2Y_LUT16_N - 1)], pp.mulC, pp.addC);
+                        /* the three table reads of a pixel on their way before the first is used (as in k_fused_t1) */
+                        const float lg = s_lut[hg & (H2Y_LUT16_N - 1)], lb = s_lut[hb & (H2Y_LUT16_N - 1)], lr = s_lut[hr & (H2Y_LUT16_N - 1)];
+#ifndef H2Y_LUT_NOBARRIER
+                        __builtin_amdgcn_sched_barrier(0);
+#endif
+                        const float g = pix_scale(lg, pp.mulY, pp.addY);
+                        const float b = pix_scale(lb, pp.mulC, pp.addC);
+                        const float r = pix_scale(lr, pp.mulC, pp.addC);
                         bool um;
                         pix_matrix<MODE, false>(pp, g, b, r, Y[col], Cb[col], Cr[col], &um);
                         const bool outside = ((hg | hb | hr) & ~(uint32_t)(H2Y_LUT16_N - 1)) != 0; /* negative, >= 2.0, inf, NaN */

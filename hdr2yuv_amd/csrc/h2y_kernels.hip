@@ -690,6 +690,18 @@ __device__ __forceinline__ float pq_sample(const pix_params &pp, int c, float ra
     any_slow |= slow;
     return pix_scale(v, c == 0 ? pp.mulY : pp.mulC, c == 0 ? pp.addY : pp.addC);
 }
+/* the same from a record already fetched (x normalised) */
+__device__ __forceinline__ float pq_sample_rec(const pix_params &pp, int c, float x, const pq_rec &rec, bool &any_slow)
+{
+    bool sl;
+    float v = pq_eval(x, rec, &sl);
+    const bool zero = f2bits(x) == 0u; /* as pq_fast(): +0.0 is outside the table but its value is a constant */
+    const bool slow = sl & !zero;
+    v = zero ? bits2f(H2Y_PQ_AT_ZERO_BITS) : v;
+    if (__builtin_expect(slow, 0)) v = pq_slow(x);
+    any_slow |= slow;
+    return pix_scale(v, c == 0 ? pp.mulY : pp.mulC, c == 0 ? pp.addY : pp.addC);
+}
 template <int IN_KIND, int OUT_KIND, int MODE, int PIPE>
 __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused2(fused_args a)
 {
@@ -746,9 +758,17 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
 #pragma unroll
                 for (int col = 0; col < 4; col++) {
                     bool odd = false; /* a sample went through pq_slow(): it may be NaN (negative input, 0/0 normalisation) */
-                    const float g = pq_sample<PIPE>(pp, 0, gv[col], sA, sB, odd);
-                    const float b = pq_sample<PIPE>(pp, 1, bv[col], sA, sB, odd);
-                    const float r = pq_sample<PIPE>(pp, 2, rv[col], sA, sB, odd);
+                    float g, b, r;
+                    if (PIPE == H2Y_PIPE_NONE) { g = gv[col]; b = bv[col]; r = rv[col]; }
+                    else {
+                        /* the six table records of a pixel on their way before the first is used */
+                        const float xg = norm1<PIPE>(pp, 0, gv[col]), xb = norm1<PIPE>(pp, 1, bv[col]), xr = norm1<PIPE>(pp, 2, rv[col]);
+                        const pq_rec cg = pq_fetch(xg, sA, sB), cb = pq_fetch(xb, sA, sB), cr = pq_fetch(xr, sA, sB);
+                        __builtin_amdgcn_sched_barrier(0);
+                        g = pq_sample_rec(pp, 0, xg, cg, odd);
+                        b = pq_sample_rec(pp, 1, xb, cb, odd);
+                        r = pq_sample_rec(pp, 2, xr, cr, odd);
+                    }
                     bool um;
                     pix_matrix<MODE, false>(pp, g, b, r, Y[col], Cb[col], Cr[col], &um);
                     /* the careful form of the matrix: IEEE divisions, the reference's NaN conversions */

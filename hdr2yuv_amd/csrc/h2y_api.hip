@@ -361,6 +361,8 @@ fused_variant pick_variant(const h2y_desc *d, const pix_params &pp, int out_kind
     return v;
 }
 
+constexpr int kMaxFramesPerLaunch = 128;
+
 int out_kind_of(const h2y_desc *d)
 {
     if (d->dst_chroma_format_idc == H2Y_CHROMA_444) return H2Y_OUT_444;
@@ -476,7 +478,9 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
     }
     const geom g = make_geom(d, h2y_fused_threads(var), var.cols8 ? 8 : 4);
     const size_t npix = (size_t)d->width * d->height;
-    const int step = out_kind == H2Y_OUT_444TMP ? kFirSubBatch : n;
+    /* one launch covers at most kMaxFramesPerLaunch frames: k_fused_t1's waves draw their tiles from one LDS counter
+     * per frame of their group (H2Y_CLAIM_FRAMES of them) */
+    const int step = out_kind == H2Y_OUT_444TMP ? kFirSubBatch : (n < kMaxFramesPerLaunch ? n : kMaxFramesPerLaunch);
     if (out_kind == H2Y_OUT_444TMP) {
         /* two halves: sub-batch i writes half i%2 while the FIR pass still reads the other */
         int rc = ensure(ctx, ctx->d_tmp, ctx->tmp_cap, (size_t)2 * kFirSubBatch * 2 * npix * sizeof(uint16_t));

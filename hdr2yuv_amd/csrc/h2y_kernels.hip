@@ -660,6 +660,48 @@ __device__ __forceinline__ tile_pos next_tile(const fused_args &a, int kind, uin
     return tile_locate(umin32(k2 * THREADS + threadIdx.x, a.tiles_per_frame - 1u), a.width, a.height, a.wq, a.wq_magic);
 }
 
+/*
+ * Waves take their tiles by ticket.
+ *
+ * The SIMD arbiter serves its oldest wave first.  With a fixed share per wave -- every wave one 64-tile
+ * slice of every chunk -- the four waves of a SIMD do not finish together: measured on C2
+ * (tools/blocktimes.py), the oldest wave of each SIMD left the frame loop at 57 % of the launch, the next
+ * at 70 %, the third at 87 %, and the last ran alone, at a third of the four-wave rate.  So the slices of
+ * a block's chunks are not tied to waves: a frame's slices are numbered (slice i = chunk i / WPB of the
+ * block's chunks of that frame, 64-tile part i % WPB) and a wave draws the next number from a counter in
+ * LDS (one ds_add_rtn per tile, claimed one tile ahead so that the prefetch knows its target).  Old
+ * waves simply draw more often; all leave a frame within one tile of each other.  One counter per frame
+ * of the group (waves drift across frame boundaries), zeroed at kernel start: H2Y_CLAIM_FRAMES bounds the
+ * frames of a group per launch (the host splits longer batches).
+ */
+#define H2Y_CLAIM_FRAMES 128
+struct wave_deal { /* a block's share of one frame, in slices */
+    uint32_t kA, kB, G, Gf, nA, total; /* first chunks and strides of the two parts, chunks in part A, slices in all */
+    __device__ __forceinline__ void set(const frame_walk &fw, uint32_t ka, uint32_t kb, uint32_t wpb)
+    {
+        kA = ka; kB = kb; G = fw.G; Gf = fw.Gf;
+        nA = fw.count_a(ka);
+        total = (nA + fw.count_b(kb)) * wpb;
+    }
+    /* first tile of slice i (WPB slices of 64 tiles per chunk of THREADS tiles) */
+    template <int THREADS> __device__ __forceinline__ uint32_t tile0(uint32_t i) const
+    {
+        constexpr uint32_t WPB = THREADS / WAVE;
+        const uint32_t j = i / WPB, sub = i % WPB;
+        const uint32_t k = j < nA ? kA + j * G : kB + (j - nA) * Gf;
+        return k * THREADS + sub * WAVE;
+    }
+};
+/* draw a number: lane 0 adds to the counter, the other lanes to scratch words of their own (no branch) */
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ uint32_t wave_claim(uint32_t *ctr, uint32_t *scratch /* [WAVE] */, bool real)
+{
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    uint32_t *p = (real && lane == 0) ? ctr : scratch + lane;
+    const uint32_t v = __hip_atomic_fetch_add((lds_u32 *)p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
 /* finish time of the block, for the host's balancing: the latest of its waves */
 __device__ __forceinline__ void block_clock_start(const fused_args &a)
 {
@@ -911,9 +953,11 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
     __shared__ uint32_t s_redo[H2Y_T1_THREADS / WAVE][H2Y_REDO_CAP];
     __shared__ pix_params s_pp;
     __shared__ redo_ctx s_rc;
+    __shared__ uint32_t s_claim[H2Y_CLAIM_FRAMES], s_scratch[WAVE];
     {
         stage16<H2Y_T1_THREADS, H2Y_T1_NREC>(a.table1, s_t1);
         stage_table<H2Y_T1_THREADS>(a.table, s_t2);
+        if (threadIdx.x < H2Y_CLAIM_FRAMES) s_claim[threadIdx.x] = 0u;
     }
     const pix_params pp = with_assumed(a.pp, a.assumed);
     t1_sens sn = a.sn;
@@ -954,7 +998,10 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
     bool have = false; /* v holds the tile this block meets next (uniform) */
     typedef in_traits<IN_KIND> IN;
     frame_walk fw;
-    for (walk_init(fw, a); fw.f < a.n_frames; fw.advance()) {
+    uint32_t fo = 0;   /* ordinal of the frame among the group's: its counter is s_claim[fo] */
+    uint32_t tick = 0; /* the slice in hand, if hold: of the frame the loop is at (or about to enter) */
+    bool hold = false; /* (have implies hold: v is tick's tile; a redo pass drops the data, not the slice) */
+    for (walk_init(fw, a); fw.f < a.n_frames; fw.advance(), fo++) {
         const int f = fw.f;
         const frame_io io = uniform_io(a.frames + f);
         const frame_io io_next = uniform_io(a.frames + (fw.has_next() ? f + (int)fw.NG : f)); /* for the prefetch across the frame boundary */
@@ -962,12 +1009,17 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
         mm.reset();
         const uint32_t id_base = (uint32_t)f * a.tiles_per_frame;
         uint32_t flagged_f = 0; /* tiles of this frame this wave sent to the list (the host steers by their share) */
-        uint32_t k;
-        bool inB;
-        bool more = fw.first(k, inB);
+        wave_deal deal, deal_n;
+        deal.set(fw, fw.kA, fw.kB, H2Y_T1_THREADS / WAVE);
+        deal_n.set(fw, fw.kA_n, fw.kB_n, H2Y_T1_THREADS / WAVE);
+        if (!hold) {
+            tick = wave_claim(&s_claim[fo], s_scratch, true);
+            hold = tick < deal.total;
+        }
+        bool more = hold;
         while (more) {
-            if (!have) { /* nothing on its way (first tile of the launch, or a block that skipped frames) */
-                t_cur = tile_locate(umin32(k * H2Y_T1_THREADS + threadIdx.x, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
+            if (!have) { /* nothing on its way (first tile of the launch, after a redo pass, or a wave that found a frame dealt out) */
+                t_cur = tile_locate(umin32(deal.tile0<H2Y_T1_THREADS>(tick) + lane, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
                 tile_load<IN_KIND>(io, t_cur, v);
             }
             /* have the data arrive here: entering the loop with loads outstanding would make the loop's
@@ -976,14 +1028,23 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
             for (int j = 0; j < 4; j++)
                 asm volatile("" ::"v"(v.g0[j]), "v"(v.b0[j]), "v"(v.r0[j]), "v"(v.g1[j]), "v"(v.b1[j]), "v"(v.r1[j]));
             do {
-                const uint32_t tt = k * H2Y_T1_THREADS + threadIdx.x;
+                const uint32_t tt = deal.tile0<H2Y_T1_THREADS>(tick) + lane;
                 tile_pos t = t_cur; /* located one iteration ago, as the prefetch target */
                 t.row1 = true;
                 const void *src[3];
-                uint32_t k2;
-                bool inB2;
-                const int kind = fw.succ(k, inB, k2, inB2);
-                const tile_pos t2 = next_tile<H2Y_T1_THREADS>(a, kind, k2, io, io_next, src, &have);
+                /* the next slice: of this frame, else of the group's next frame, else none (the request repeats the current tile) */
+                const uint32_t n1 = wave_claim(&s_claim[fo], s_scratch, true);
+                const bool same = n1 < deal.total;
+                const bool try_next = !same && fw.has_next();
+                const uint32_t n2 = wave_claim(&s_claim[(fo + 1u) & (H2Y_CLAIM_FRAMES - 1u)], s_scratch, try_next);
+                const bool nextf = try_next && n2 < deal_n.total;
+                const int kind = same ? 1 : nextf ? 2 : 0;
+                const uint32_t tick2 = same ? n1 : nextf ? n2 : tick;
+                const uint32_t tt2 = (nextf ? deal_n.tile0<H2Y_T1_THREADS>(tick2) : deal.tile0<H2Y_T1_THREADS>(tick2)) + lane;
+                hold = have = kind != 0;
+#pragma unroll
+                for (int c = 0; c < 3; c++) src[c] = kind == 2 ? io_next.in[c] : io.in[c];
+                const tile_pos t2 = tile_locate(umin32(tt2, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
 
                 tile_out o;
                 uint32_t sb[2], sr[2]; /* 2x2 box: chroma sums of the two blocks */
@@ -1084,8 +1145,7 @@ if (PIPE == H2Y_PIPE_PQ_IDENT) {
                     flagged_f += (uint32_t)__popcll(m);
                 }
                 more = kind == 1;
-                k = k2;
-                inB = inB2;
+                tick = tick2;
             } while (more && n_redo < WAVE);
             if (n_redo >= WAVE) { /* 64 tiles to redo: one per lane */
                 n_redo -= WAVE;

@@ -104,6 +104,10 @@ struct frame_walk {
         inB2 = same1 ? inB : toB ? true : next ? !nA : inB;
         return (same1 || toB) ? 1 : next ? 2 : 0;
     }
+    /* how many chunks of parts A and B this block owns in the current frame / the group's next one
+     * (they are kA, kA + G, ... below cpfA and kB, kB + Gf, ... below cpf) */
+    H2Y_FN uint32_t count_a(uint32_t k) const { return k < cpfA ? (cpfA - 1u - k) / G + 1u : 0u; }
+    H2Y_FN uint32_t count_b(uint32_t k) const { return k < cpf ? (cpf - 1u - k) / Gf + 1u : 0u; }
     /* a block's slot in the per-frame arrays: [frame][block of the group] */
     H2Y_FN size_t slot() const { return (size_t)f * G + bi; }
 };

@@ -645,21 +645,6 @@ __device__ __forceinline__ void walk_init(frame_walk &fw, const fused_args &a)
 /* this wave's slot in the per-frame arrays: [frame][block of the group][wave] */
 __device__ __forceinline__ size_t walk_slot(const frame_walk &fw, uint32_t waves) { return fw.slot() * waves + threadIdx.x / WAVE; }
 
-/* The branch-free loop forms (k_fused2, k_fused_t1, k_fused_lut16) ask for the next tile while they
- * work on the current one: the tile of chunk k2 = frame_walk::succ(k) -- in the same frame, in the
- * group's next frame, or nowhere: then the current tile is simply asked for again (the request is
- * unconditional).  Returns the next tile's position and which frame's planes to read; *have says whether
- * the data requested is the tile the block meets next. */
-template <int THREADS>
-__device__ __forceinline__ tile_pos next_tile(const fused_args &a, int kind, uint32_t k2, const frame_io &io, const frame_io &io_next,
-                                              const void *(&src)[3], bool *have)
-{
-    *have = kind != 0;
-#pragma unroll
-    for (int c = 0; c < 3; c++) src[c] = kind == 2 ? io_next.in[c] : io.in[c];
-    return tile_locate(umin32(k2 * THREADS + threadIdx.x, a.tiles_per_frame - 1u), a.width, a.height, a.wq, a.wq_magic);
-}
-
 /*
  * Waves take their tiles by ticket.
  *
@@ -700,6 +685,22 @@ __device__ __forceinline__ uint32_t wave_claim(uint32_t *ctr, uint32_t *scratch 
     uint32_t *p = (real && lane == 0) ? ctr : scratch + lane;
     const uint32_t v = __hip_atomic_fetch_add((lds_u32 *)p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return __builtin_amdgcn_readfirstlane(v);
+}
+
+/* The slice after the one in hand: of this frame, else of the group's next frame (kind 2), else none (kind 0:
+ * the request repeats the current tile).  Returns the first tile of that slice. */
+template <int THREADS>
+__device__ __forceinline__ uint32_t ticket_next(const wave_deal &deal, const wave_deal &deal_n, uint32_t *claim, uint32_t *scratch, uint32_t fo,
+                                                bool has_next, uint32_t tick, int *kind, uint32_t *tick2)
+{
+    const uint32_t n1 = wave_claim(&claim[fo], scratch, true);
+    const bool same = n1 < deal.total;
+    const bool try_next = !same && has_next;
+    const uint32_t n2 = wave_claim(&claim[(fo + 1u) & (H2Y_CLAIM_FRAMES - 1u)], scratch, try_next);
+    const bool nextf = try_next && n2 < deal_n.total;
+    *kind = same ? 1 : nextf ? 2 : 0;
+    *tick2 = same ? n1 : nextf ? n2 : tick;
+    return nextf ? deal_n.tile0<THREADS>(*tick2) : deal.tile0<THREADS>(*tick2);
 }
 
 /* finish time of the block, for the host's balancing: the latest of its waves */
@@ -750,41 +751,51 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
     __shared__ pq_recA s_tab[PIPE == H2Y_PIPE_NONE ? 1 : 2 * H2Y_PQ_NREC]; /* A records, then B records */
     const pq_recA *sA = s_tab;
     const pq_recB *sB = reinterpret_cast<const pq_recB *>(s_tab + (PIPE == H2Y_PIPE_NONE ? 0 : H2Y_PQ_NREC));
+    __shared__ uint32_t s_claim[H2Y_CLAIM_FRAMES], s_scratch[WAVE];
     if (PIPE != H2Y_PIPE_NONE) stage_table<H2Y_FUSED_THREADS>(a.table, s_tab);
+    if (threadIdx.x < H2Y_CLAIM_FRAMES) s_claim[threadIdx.x] = 0u;
     const pix_params pp = with_assumed(a.pp, a.assumed);
     __syncthreads();
 
     block_clock_start(a);
     const uint32_t W = a.width, H = a.height;
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
     tile_in v;         /* the tile being worked on; refilled row by row with the next one */
     tile_pos t_cur;    /* and where it is */
-    bool have = false; /* v holds the tile this block meets next (uniform) */
+    bool have = false; /* v holds the tile this wave meets next (uniform) */
     typedef in_traits<IN_KIND> IN;
     frame_walk fw;
-    for (walk_init(fw, a); fw.f < a.n_frames; fw.advance()) {
+    uint32_t fo = 0, tick = 0; /* waves take their tiles by ticket: see wave_deal */
+    for (walk_init(fw, a); fw.f < a.n_frames; fw.advance(), fo++) {
         const int f = fw.f;
         const frame_io io = uniform_io(a.frames + f);
         const frame_io io_next = uniform_io(a.frames + (fw.has_next() ? f + (int)fw.NG : f));
         mm6 mm;
         mm.reset();
-        uint32_t k;
-        bool inB;
-        bool more = fw.first(k, inB);
+        wave_deal deal, deal_n;
+        deal.set(fw, fw.kA, fw.kB, H2Y_FUSED_THREADS / WAVE);
+        deal_n.set(fw, fw.kA_n, fw.kB_n, H2Y_FUSED_THREADS / WAVE);
+        if (!have) tick = wave_claim(&s_claim[fo], s_scratch, true);
+        bool more = tick < deal.total; /* (a slice carried over from the previous frame is always below the total) */
         if (!have && more) {
-            t_cur = tile_locate(umin32(k * H2Y_FUSED_THREADS + threadIdx.x, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
+            t_cur = tile_locate(umin32(deal.tile0<H2Y_FUSED_THREADS>(tick) + lane, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
             tile_load<IN_KIND>(io, t_cur, v);
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 asm volatile("" ::"v"(v.g0[j]), "v"(v.b0[j]), "v"(v.r0[j]), "v"(v.g1[j]), "v"(v.b1[j]), "v"(v.r1[j]));
         }
+        if (!more) have = false;
         while (more) {
             tile_pos t = t_cur;
             t.row1 = true;
             const void *src[3];
-            uint32_t k2;
-            bool inB2;
-            const int kind = fw.succ(k, inB, k2, inB2);
-            const tile_pos t2 = next_tile<H2Y_FUSED_THREADS>(a, kind, k2, io, io_next, src, &have);
+            int kind;
+            uint32_t tick2;
+            const uint32_t tt2 = ticket_next<H2Y_FUSED_THREADS>(deal, deal_n, s_claim, s_scratch, fo, fw.has_next(), tick, &kind, &tick2) + lane;
+            have = kind != 0;
+#pragma unroll
+            for (int c = 0; c < 3; c++) src[c] = kind == 2 ? io_next.in[c] : io.in[c];
+            const tile_pos t2 = tile_locate(umin32(tt2, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
 
             tile_out o;
             uint32_t sb[2], sr[2];
@@ -830,8 +841,7 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
             IN::load4q(src[2], t2.q1, v.r1);
             t_cur = t2;
             more = kind == 1;
-            k = k2;
-            inB = inB2;
+            tick = tick2;
         }
         wave_store_mm(mm, a.partial + walk_slot(fw, H2Y_FUSED_THREADS / WAVE) * 6);
     }
@@ -1032,15 +1042,9 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
                 tile_pos t = t_cur; /* located one iteration ago, as the prefetch target */
                 t.row1 = true;
                 const void *src[3];
-                /* the next slice: of this frame, else of the group's next frame, else none (the request repeats the current tile) */
-                const uint32_t n1 = wave_claim(&s_claim[fo], s_scratch, true);
-                const bool same = n1 < deal.total;
-                const bool try_next = !same && fw.has_next();
-                const uint32_t n2 = wave_claim(&s_claim[(fo + 1u) & (H2Y_CLAIM_FRAMES - 1u)], s_scratch, try_next);
-                const bool nextf = try_next && n2 < deal_n.total;
-                const int kind = same ? 1 : nextf ? 2 : 0;
-                const uint32_t tick2 = same ? n1 : nextf ? n2 : tick;
-                const uint32_t tt2 = (nextf ? deal_n.tile0<H2Y_T1_THREADS>(tick2) : deal.tile0<H2Y_T1_THREADS>(tick2)) + lane;
+                int kind;
+                uint32_t tick2;
+                const uint32_t tt2 = ticket_next<H2Y_T1_THREADS>(deal, deal_n, s_claim, s_scratch, fo, fw.has_next(), tick, &kind, &tick2) + lane;
                 hold = have = kind != 0;
 #pragma unroll
                 for (int c = 0; c < 3; c++) src[c] = kind == 2 ? io_next.in[c] : io.in[c];
@@ -1158,6 +1162,9 @@ if (PIPE == H2Y_PIPE_PQ_IDENT) {
         wave_store_mm(mm, a.partial + walk_slot(fw, H2Y_T1_THREADS / WAVE) * 6);
         if (a.redo_count && lane == 0) a.redo_count[walk_slot(fw, H2Y_T1_THREADS / WAVE)] = flagged_f;
     }
+#ifdef H2Y_BLOCK_TIMES /* blocks 0..3: when each wave left the frame loop */
+    if (blockIdx.x < 4 && lane == 0) g_block_times[2 * (800 + blockIdx.x * 16 + wave)] = wall_clock64();
+#endif
     if (n_redo) redo_pass<IN_KIND, OUT_KIND, MODE, PIPE>(&s_rc, &s_pp, s_t2, my_list, 0u, n_redo);
     block_clock_end(a);
 #ifdef H2Y_BLOCK_TIMES
@@ -1234,8 +1241,10 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
     constexpr int NH = COLS / 4; /* 4-column halves per tile */
     __shared__ float s_lut[H2Y_LUT16_N];
     __shared__ pix_params s_pp;
+    __shared__ uint32_t s_claim[H2Y_CLAIM_FRAMES], s_scratch[WAVE];
     {
         stage16<H2Y_FUSED_THREADS, H2Y_LUT16_N / 4>(a.lut16, s_lut);
+        if (threadIdx.x < H2Y_CLAIM_FRAMES) s_claim[threadIdx.x] = 0u;
     }
     const pix_params pp = with_assumed(a.pp, a.assumed);
     if (threadIdx.x == 0) s_pp = pp;
@@ -1248,8 +1257,10 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
     RV raw[3][2];   /* the tile being worked on, raw halves: [plane][row], COLS samples each */
     tile_pos t_cur;
     bool have = false;
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
     frame_walk fw;
-    for (walk_init(fw, a); fw.f < a.n_frames; fw.advance()) {
+    uint32_t fo = 0, tick = 0; /* waves take their tiles by ticket: see wave_deal */
+    for (walk_init(fw, a); fw.f < a.n_frames; fw.advance(), fo++) {
         const int f = fw.f;
         const frame_io io = uniform_io(a.frames + f);
         const frame_io io_next = uniform_io(a.frames + (fw.has_next() ? f + (int)fw.NG : f));
@@ -1260,11 +1271,14 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
             mn[c] = 0x7C007C00u; /* +inf stands in for FLT_MAX (common.cpp:118): no finite or infinite sample is "< FLT_MAX" unless it is finite */
             mx[c] = 0x00000000u; /* +0: FLT_MIN (1.2e-38) is below the smallest half; (int) of either is 0 */
         }
-        uint32_t k;
-        bool inB;
-        bool more = fw.first(k, inB);
+        wave_deal deal, deal_n;
+        deal.set(fw, fw.kA, fw.kB, H2Y_FUSED_THREADS / WAVE);
+        deal_n.set(fw, fw.kA_n, fw.kB_n, H2Y_FUSED_THREADS / WAVE);
+        if (!have) tick = wave_claim(&s_claim[fo], s_scratch, true);
+        bool more = tick < deal.total;
+        if (!more) have = false;
         if (!have && more) {
-            t_cur = tile_locate(umin32(k * H2Y_FUSED_THREADS + threadIdx.x, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
+            t_cur = tile_locate(umin32(deal.tile0<H2Y_FUSED_THREADS>(tick) + lane, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 raw[c][0] = gload_nt<RV>(io.in[c], t_cur.q0);
@@ -1279,10 +1293,13 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
             tile_pos t = t_cur;
             t.row1 = true;
             const void *src[3];
-            uint32_t k2;
-            bool inB2;
-            const int kind = fw.succ(k, inB, k2, inB2);
-            const tile_pos t2 = next_tile<H2Y_FUSED_THREADS>(a, kind, k2, io, io_next, src, &have);
+            int kind;
+            uint32_t tick2;
+            const uint32_t tt2 = ticket_next<H2Y_FUSED_THREADS>(deal, deal_n, s_claim, s_scratch, fo, fw.has_next(), tick, &kind, &tick2) + lane;
+            have = kind != 0;
+#pragma unroll
+            for (int c = 0; c < 3; c++) src[c] = kind == 2 ? io_next.in[c] : io.in[c];
+            const tile_pos t2 = tile_locate(umin32(tt2, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
             tile_out o[NH];
             uint32_t sb[NH][2], sr[NH][2];
 #pragma unroll
@@ -1333,8 +1350,7 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
             for (int c = 0; c < 3; c++) raw[c][1] = gload_nt<RV>(src[c], t2.q1);
             t_cur = t2;
             more = kind == 1;
-            k = k2;
-            inB = inB2;
+            tick = tick2;
         }
         mm6 mm;
 #pragma unroll

@@ -58,6 +58,24 @@ static void check(uint32_t grid, uint32_t groups, uint32_t layout, uint32_t mask
     for (int f = 0; f < nfr && !bad; f++)
         for (uint32_t c = 0; c < cpf; c++)
             if (seen[f][c] != 1 || group_of[f][c] != f % (int)groups) { bad = true; break; }
+    /* the closed form the kernels' ticket dealing uses (wave_deal in h2y_kernels.hip): a block's chunks of a frame
+     * are kA + j G (j < count_a) and kB + j Gf (j < count_b); and kA_n / kB_n are the next frame's kA / kB */
+    std::vector<std::vector<int>> seen2(nfr, std::vector<int>(cpf, 0));
+    for (uint32_t b = 0; b < grid && !bad; b++) {
+        frame_walk fw;
+        bool have_n = false;
+        uint32_t ka_n = 0, kb_n = 0;
+        for (fw.init(a, b, grid); fw.f < nfr; fw.advance()) {
+            if (have_n && (fw.kA != ka_n || fw.kB != kb_n)) { bad = true; break; }
+            have_n = true; ka_n = fw.kA_n; kb_n = fw.kB_n;
+            const uint32_t na = fw.count_a(fw.kA), nb = fw.count_b(fw.kB);
+            for (uint32_t j = 0; j < na; j++) { const uint32_t k = fw.kA + j * fw.G; if (k >= cpf) { bad = true; break; } seen2[fw.f][k]++; }
+            for (uint32_t j = 0; j < nb; j++) { const uint32_t k = fw.kB + j * fw.Gf; if (k >= cpf) { bad = true; break; } seen2[fw.f][k]++; }
+        }
+    }
+    for (int f = 0; f < nfr && !bad; f++)
+        for (uint32_t c = 0; c < cpf; c++)
+            if (seen2[f][c] != 1) { bad = true; break; }
     n_cfg++;
     if (bad) {
         n_bad++;

@@ -687,6 +687,13 @@ __device__ __forceinline__ uint32_t wave_claim(uint32_t *ctr, uint32_t *scratch 
     return __builtin_amdgcn_readfirstlane(v);
 }
 
+/* the two halves of wave_claim(): the add goes out early, its result is read when the prefetch needs it */
+__device__ __forceinline__ uint32_t wave_claim_issue(uint32_t *ctr, uint32_t *scratch)
+{
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    uint32_t *p = lane == 0 ? ctr : scratch + lane;
+    return __hip_atomic_fetch_add((lds_u32 *)p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 /* The slice after the one in hand: of this frame, else of the group's next frame (kind 2), else none (kind 0:
  * the request repeats the current tile).  Returns the first tile of that slice. */
 template <int THREADS>
@@ -1044,11 +1051,9 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
                 const void *src[3];
                 int kind;
                 uint32_t tick2;
-                const uint32_t tt2 = ticket_next<H2Y_T1_THREADS>(deal, deal_n, s_claim, s_scratch, fo, fw.has_next(), tick, &kind, &tick2) + lane;
-                hold = have = kind != 0;
-#pragma unroll
-                for (int c = 0; c < 3; c++) src[c] = kind == 2 ? io_next.in[c] : io.in[c];
-                const tile_pos t2 = tile_locate(umin32(tt2, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
+                tile_pos t2;
+                /* the next slice's number is asked for here and read after row 0, when the prefetch needs it */
+                const uint32_t n1v = wave_claim_issue(&s_claim[fo], s_scratch);
 
                 tile_out o;
                 uint32_t sb[2], sr[2]; /* 2x2 box: chroma sums of the two blocks */
@@ -1121,6 +1126,27 @@ if (PIPE == H2Y_PIPE_PQ_IDENT) {
                     }
                     row_pack<OUT_KIND, true>(pp, row, Y, Cb, Cr, o, sb, sr);
                     if (row == 0) { /* row 0 of the next tile, into the registers just read for the last time */
+                        {
+                            const uint32_t n1 = __builtin_amdgcn_readfirstlane(n1v);
+                            const bool same = n1 < deal.total;
+                            uint32_t tt2;
+                            if (__builtin_expect(same, 1)) {
+                                kind = 1;
+                                tick2 = n1;
+                                tt2 = deal.tile0<H2Y_T1_THREADS>(n1);
+                            } else { /* this frame is dealt out: a slice of the group's next frame, if there is one */
+                                const bool try_next = fw.has_next();
+                                const uint32_t n2 = wave_claim(&s_claim[(fo + 1u) & (H2Y_CLAIM_FRAMES - 1u)], s_scratch, try_next);
+                                const bool nextf = try_next && n2 < deal_n.total;
+                                kind = nextf ? 2 : 0;
+                                tick2 = nextf ? n2 : tick;
+                                tt2 = nextf ? deal_n.tile0<H2Y_T1_THREADS>(n2) : deal.tile0<H2Y_T1_THREADS>(tick);
+                            }
+                            hold = have = kind != 0;
+#pragma unroll
+                            for (int c = 0; c < 3; c++) src[c] = kind == 2 ? io_next.in[c] : io.in[c];
+                            t2 = tile_locate(umin32(tt2 + lane, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
+                        }
                         IN::load4q(src[0], t2.q0, v.g0);
                         IN::load4q(src[1], t2.q0, v.b0);
                         IN::load4q(src[2], t2.q0, v.r0);

@@ -694,20 +694,24 @@ __device__ __forceinline__ uint32_t wave_claim_issue(uint32_t *ctr, uint32_t *sc
     uint32_t *p = lane == 0 ? ctr : scratch + lane;
     return __hip_atomic_fetch_add((lds_u32 *)p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-/* The slice after the one in hand: of this frame, else of the group's next frame (kind 2), else none (kind 0:
- * the request repeats the current tile).  Returns the first tile of that slice. */
+/* The slice after the one in hand, from the number asked for with wave_claim_issue() at the top of the tile: of
+ * this frame (kind 1), else -- this frame is dealt out -- of the group's next frame if there is one (kind 2), else
+ * none (kind 0: the request repeats the current tile).  Returns the first tile of that slice. */
 template <int THREADS>
-__device__ __forceinline__ uint32_t ticket_next(const wave_deal &deal, const wave_deal &deal_n, uint32_t *claim, uint32_t *scratch, uint32_t fo,
-                                                bool has_next, uint32_t tick, int *kind, uint32_t *tick2)
+__device__ __forceinline__ uint32_t ticket_resolve(uint32_t n1v, const wave_deal &deal, const wave_deal &deal_n, uint32_t *claim, uint32_t *scratch,
+                                                   uint32_t fo, bool has_next, uint32_t tick, int *kind, uint32_t *tick2)
 {
-    const uint32_t n1 = wave_claim(&claim[fo], scratch, true);
-    const bool same = n1 < deal.total;
-    const bool try_next = !same && has_next;
-    const uint32_t n2 = wave_claim(&claim[(fo + 1u) & (H2Y_CLAIM_FRAMES - 1u)], scratch, try_next);
-    const bool nextf = try_next && n2 < deal_n.total;
-    *kind = same ? 1 : nextf ? 2 : 0;
-    *tick2 = same ? n1 : nextf ? n2 : tick;
-    return nextf ? deal_n.tile0<THREADS>(*tick2) : deal.tile0<THREADS>(*tick2);
+    const uint32_t n1 = __builtin_amdgcn_readfirstlane(n1v);
+    if (__builtin_expect(n1 < deal.total, 1)) {
+        *kind = 1;
+        *tick2 = n1;
+        return deal.tile0<THREADS>(n1);
+    }
+    const uint32_t n2 = wave_claim(&claim[(fo + 1u) & (H2Y_CLAIM_FRAMES - 1u)], scratch, has_next);
+    const bool nextf = has_next && n2 < deal_n.total;
+    *kind = nextf ? 2 : 0;
+    *tick2 = nextf ? n2 : tick;
+    return nextf ? deal_n.tile0<THREADS>(n2) : deal.tile0<THREADS>(tick);
 }
 
 /* finish time of the block, for the host's balancing: the latest of its waves */
@@ -798,11 +802,8 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
             const void *src[3];
             int kind;
             uint32_t tick2;
-            const uint32_t tt2 = ticket_next<H2Y_FUSED_THREADS>(deal, deal_n, s_claim, s_scratch, fo, fw.has_next(), tick, &kind, &tick2) + lane;
-            have = kind != 0;
-#pragma unroll
-            for (int c = 0; c < 3; c++) src[c] = kind == 2 ? io_next.in[c] : io.in[c];
-            const tile_pos t2 = tile_locate(umin32(tt2, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
+            tile_pos t2;
+            const uint32_t n1v = wave_claim_issue(&s_claim[fo], s_scratch); /* read after row 0, when the prefetch needs it */
 
             tile_out o;
             uint32_t sb[2], sr[2];
@@ -836,6 +837,11 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
                 }
                 row_pack<OUT_KIND, IN_KIND != H2Y_IN_U16>(pp, row, Y, Cb, Cr, o, sb, sr);
                 if (row == 0) {
+                    const uint32_t tt2 = ticket_resolve<H2Y_FUSED_THREADS>(n1v, deal, deal_n, s_claim, s_scratch, fo, fw.has_next(), tick, &kind, &tick2);
+                    have = kind != 0;
+#pragma unroll
+                    for (int c = 0; c < 3; c++) src[c] = kind == 2 ? io_next.in[c] : io.in[c];
+                    t2 = tile_locate(umin32(tt2 + lane, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
                     IN::load4q(src[0], t2.q0, v.g0);
                     IN::load4q(src[1], t2.q0, v.b0);
                     IN::load4q(src[2], t2.q0, v.r0);
@@ -1126,7 +1132,7 @@ if (PIPE == H2Y_PIPE_PQ_IDENT) {
                     }
                     row_pack<OUT_KIND, true>(pp, row, Y, Cb, Cr, o, sb, sr);
                     if (row == 0) { /* row 0 of the next tile, into the registers just read for the last time */
-                        {
+                        { /* (spelled out: through ticket_resolve() the same code came out 3 % slower here) */
                             const uint32_t n1 = __builtin_amdgcn_readfirstlane(n1v);
                             const bool same = n1 < deal.total;
                             uint32_t tt2;
@@ -1321,11 +1327,8 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
             const void *src[3];
             int kind;
             uint32_t tick2;
-            const uint32_t tt2 = ticket_next<H2Y_FUSED_THREADS>(deal, deal_n, s_claim, s_scratch, fo, fw.has_next(), tick, &kind, &tick2) + lane;
-            have = kind != 0;
-#pragma unroll
-            for (int c = 0; c < 3; c++) src[c] = kind == 2 ? io_next.in[c] : io.in[c];
-            const tile_pos t2 = tile_locate(umin32(tt2, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
+            tile_pos t2;
+            const uint32_t n1v = wave_claim_issue(&s_claim[fo], s_scratch); /* read after row 0, when the prefetch needs it */
             tile_out o[NH];
             uint32_t sb[NH][2], sr[NH][2];
 #pragma unroll
@@ -1365,6 +1368,11 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
                     row_pack<OUT_KIND, true>(pp, row, Y, Cb, Cr, o[hf], sb[hf], sr[hf]);
                 }
                 if (row == 0) {
+                    const uint32_t tt2 = ticket_resolve<H2Y_FUSED_THREADS>(n1v, deal, deal_n, s_claim, s_scratch, fo, fw.has_next(), tick, &kind, &tick2);
+                    have = kind != 0;
+#pragma unroll
+                    for (int c = 0; c < 3; c++) src[c] = kind == 2 ? io_next.in[c] : io.in[c];
+                    t2 = tile_locate(umin32(tt2 + lane, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
 #pragma unroll
                     for (int c = 0; c < 3; c++) raw[c][0] = gload_nt<RV>(src[c], t2.q0);
                     __builtin_amdgcn_sched_barrier(0);

@@ -15,6 +15,12 @@
 #define H2Y_FUSED_MINWAVES 4 /* waves per SIMD the fused kernel is register-budgeted for: 2 blocks of 512 per CU */
 #endif
 
+/* k_fused2 / k_fused_lut16: one block of 1024 per CU -- all sixteen waves of a CU draw their tiles from one
+ * counter (wave_deal); with two blocks of 512 the older block's waves run ahead of the younger's */
+#ifndef H2Y_LOOP_THREADS
+#define H2Y_LOOP_THREADS 1024
+#endif
+
 #define H2Y_LUT16_N 16384 /* halves 0x0000..0x3FFF = [0, 2) */
 
 enum { H2Y_IN_F32 = 0, H2Y_IN_F16 = 1, H2Y_IN_U16 = 2 };

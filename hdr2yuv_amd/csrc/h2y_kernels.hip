@@ -757,13 +757,13 @@ __device__ __forceinline__ float pq_sample_rec(const pix_params &pp, int c, floa
     return pix_scale(v, c == 0 ? pp.mulY : pp.mulC, c == 0 ? pp.addY : pp.addC);
 }
 template <int IN_KIND, int OUT_KIND, int MODE, int PIPE>
-__global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused2(fused_args a)
+__global__ __launch_bounds__(H2Y_LOOP_THREADS) void k_fused2(fused_args a)
 {
     __shared__ pq_recA s_tab[PIPE == H2Y_PIPE_NONE ? 1 : 2 * H2Y_PQ_NREC]; /* A records, then B records */
     const pq_recA *sA = s_tab;
     const pq_recB *sB = reinterpret_cast<const pq_recB *>(s_tab + (PIPE == H2Y_PIPE_NONE ? 0 : H2Y_PQ_NREC));
     __shared__ uint32_t s_claim[H2Y_CLAIM_FRAMES], s_scratch[WAVE];
-    if (PIPE != H2Y_PIPE_NONE) stage_table<H2Y_FUSED_THREADS>(a.table, s_tab);
+    if (PIPE != H2Y_PIPE_NONE) stage_table<H2Y_LOOP_THREADS>(a.table, s_tab);
     if (threadIdx.x < H2Y_CLAIM_FRAMES) s_claim[threadIdx.x] = 0u;
     const pix_params pp = with_assumed(a.pp, a.assumed);
     __syncthreads();
@@ -784,12 +784,12 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
         mm6 mm;
         mm.reset();
         wave_deal deal, deal_n;
-        deal.set(fw, fw.kA, fw.kB, H2Y_FUSED_THREADS / WAVE);
-        deal_n.set(fw, fw.kA_n, fw.kB_n, H2Y_FUSED_THREADS / WAVE);
+        deal.set(fw, fw.kA, fw.kB, H2Y_LOOP_THREADS / WAVE);
+        deal_n.set(fw, fw.kA_n, fw.kB_n, H2Y_LOOP_THREADS / WAVE);
         if (!have) tick = wave_claim(&s_claim[fo], s_scratch, true);
         bool more = tick < deal.total; /* (a slice carried over from the previous frame is always below the total) */
         if (!have && more) {
-            t_cur = tile_locate(umin32(deal.tile0<H2Y_FUSED_THREADS>(tick) + lane, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
+            t_cur = tile_locate(umin32(deal.tile0<H2Y_LOOP_THREADS>(tick) + lane, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
             tile_load<IN_KIND>(io, t_cur, v);
 #pragma unroll
             for (int j = 0; j < 4; j++)
@@ -837,7 +837,7 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
                 }
                 row_pack<OUT_KIND, IN_KIND != H2Y_IN_U16>(pp, row, Y, Cb, Cr, o, sb, sr);
                 if (row == 0) {
-                    const uint32_t tt2 = ticket_resolve<H2Y_FUSED_THREADS>(n1v, deal, deal_n, s_claim, s_scratch, fo, fw.has_next(), tick, &kind, &tick2);
+                    const uint32_t tt2 = ticket_resolve<H2Y_LOOP_THREADS>(n1v, deal, deal_n, s_claim, s_scratch, fo, fw.has_next(), tick, &kind, &tick2);
                     have = kind != 0;
 #pragma unroll
                     for (int c = 0; c < 3; c++) src[c] = kind == 2 ? io_next.in[c] : io.in[c];
@@ -856,7 +856,7 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
             more = kind == 1;
             tick = tick2;
         }
-        wave_store_mm(mm, a.partial + walk_slot(fw, H2Y_FUSED_THREADS / WAVE) * 6);
+        wave_store_mm(mm, a.partial + walk_slot(fw, H2Y_LOOP_THREADS / WAVE) * 6);
     }
     block_clock_end(a);
 }
@@ -1267,7 +1267,7 @@ __device__ __forceinline__ void tile_store8(const frame_io &io, const tile_pos &
 }
 
 template <int OUT_KIND, int MODE, int COLS>
-__global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused_lut16(fused_args a)
+__global__ __launch_bounds__(H2Y_LOOP_THREADS) void k_fused_lut16(fused_args a)
 {
     typedef typename lut16_raw<COLS>::type RV;
     constexpr int NH = COLS / 4; /* 4-column halves per tile */
@@ -1275,7 +1275,7 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
     __shared__ pix_params s_pp;
     __shared__ uint32_t s_claim[H2Y_CLAIM_FRAMES], s_scratch[WAVE];
     {
-        stage16<H2Y_FUSED_THREADS, H2Y_LUT16_N / 4>(a.lut16, s_lut);
+        stage16<H2Y_LOOP_THREADS, H2Y_LUT16_N / 4>(a.lut16, s_lut);
         if (threadIdx.x < H2Y_CLAIM_FRAMES) s_claim[threadIdx.x] = 0u;
     }
     const pix_params pp = with_assumed(a.pp, a.assumed);
@@ -1304,13 +1304,13 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
             mx[c] = 0x00000000u; /* +0: FLT_MIN (1.2e-38) is below the smallest half; (int) of either is 0 */
         }
         wave_deal deal, deal_n;
-        deal.set(fw, fw.kA, fw.kB, H2Y_FUSED_THREADS / WAVE);
-        deal_n.set(fw, fw.kA_n, fw.kB_n, H2Y_FUSED_THREADS / WAVE);
+        deal.set(fw, fw.kA, fw.kB, H2Y_LOOP_THREADS / WAVE);
+        deal_n.set(fw, fw.kA_n, fw.kB_n, H2Y_LOOP_THREADS / WAVE);
         if (!have) tick = wave_claim(&s_claim[fo], s_scratch, true);
         bool more = tick < deal.total;
         if (!more) have = false;
         if (!have && more) {
-            t_cur = tile_locate(umin32(deal.tile0<H2Y_FUSED_THREADS>(tick) + lane, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
+            t_cur = tile_locate(umin32(deal.tile0<H2Y_LOOP_THREADS>(tick) + lane, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 raw[c][0] = gload_nt<RV>(io.in[c], t_cur.q0);
@@ -1368,7 +1368,7 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
                     row_pack<OUT_KIND, true>(pp, row, Y, Cb, Cr, o[hf], sb[hf], sr[hf]);
                 }
                 if (row == 0) {
-                    const uint32_t tt2 = ticket_resolve<H2Y_FUSED_THREADS>(n1v, deal, deal_n, s_claim, s_scratch, fo, fw.has_next(), tick, &kind, &tick2);
+                    const uint32_t tt2 = ticket_resolve<H2Y_LOOP_THREADS>(n1v, deal, deal_n, s_claim, s_scratch, fo, fw.has_next(), tick, &kind, &tick2);
                     have = kind != 0;
 #pragma unroll
                     for (int c = 0; c < 3; c++) src[c] = kind == 2 ? io_next.in[c] : io.in[c];
@@ -1396,7 +1396,7 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused
             mm.lo[c] = mm.lo[c] > 65504.0f ? 3.402823466e+38f : mm.lo[c]; /* still +inf: no sample was below FLT_MAX */
             mm.hi[c] = mm.hi[c] <= 0.0f ? 1.175494351e-38f : mm.hi[c];
         }
-        wave_store_mm(mm, a.partial + walk_slot(fw, H2Y_FUSED_THREADS / WAVE) * 6);
+        wave_store_mm(mm, a.partial + walk_slot(fw, H2Y_LOOP_THREADS / WAVE) * 6);
     }
     block_clock_end(a);
 }
@@ -1851,7 +1851,11 @@ bool h2y_fused_grouped(const fused_variant &v)
     const char *n = h2y_fused_name(v); /* the loop-form kernels: k_fused2, k_fused_t1, k_fused_lut16 */
     return !strcmp(n, "k_fused2") || !strcmp(n, "k_fused_t1") || !strcmp(n, "k_fused_lut16");
 }
-int h2y_fused_threads(const fused_variant &v) { return (v.pipe == 4 || v.pipe == 5) ? H2Y_T1_THREADS : H2Y_FUSED_THREADS; }
+int h2y_fused_threads(const fused_variant &v)
+{
+    if (v.pipe == 4 || v.pipe == 5) return H2Y_T1_THREADS;
+    return h2y_fused_grouped(v) ? H2Y_LOOP_THREADS : H2Y_FUSED_THREADS; /* k_fused2 / k_fused_lut16 : k_fused / k_fused_narrow */
+}
 
 static fused_fn pick_fused(const fused_variant &v)
 {

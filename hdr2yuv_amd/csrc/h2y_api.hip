@@ -73,6 +73,7 @@ struct h2y_ctx {
     /* per-batch device arrays */
     frame_io *d_frames = nullptr, *h_frames = nullptr;
     size_t frames_cap = 0;
+    std::vector<frame_io> dev_frames; /* what d_frames holds (size frames_cap once anything was copied; cleared when d_frames is reallocated) */
     float *d_partial = nullptr;
     uint32_t *d_redo = nullptr; /* k_fused_t1: per-wave counts of redone tiles */
     uint32_t *d_low = nullptr;  /* k_fused_t1: per-frame flag "a sample <= -1 was seen" (zero between launches) */
@@ -492,17 +493,25 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         const int half = sub & 1;
         if (out_kind == H2Y_OUT_444TMP && ctx->fir_used[half]) /* scratch half still being read by an earlier FIR pass? */
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_fir[half], 0));
-        /* frame descriptors: host -> device (tiny) */
+        /* frame descriptors: host -> device (tiny) -- unless the device already holds exactly these (a caller
+         * cycling through the same buffers): one stream operation less in front of the kernel */
+        bool on_device = ctx->dev_frames.size() == ctx->frames_cap;
+        if (!on_device) ctx->dev_frames.assign(ctx->frames_cap, frame_io{});
         for (int i = 0; i < nf; i++) {
             frame_io io = frames[f0 + i];
             if (out_kind == H2Y_OUT_444TMP) {
                 io.tmp_cb = ctx->d_tmp + ((size_t)half * kFirSubBatch + i) * 2 * npix;
                 io.tmp_cr = io.tmp_cb + npix;
             }
-            ctx->h_frames[ctx->slot_base + f0 + i] = io;
+            const size_t idx = (size_t)ctx->slot_base + f0 + i;
+            on_device = on_device && memcmp(&ctx->dev_frames[idx], &io, sizeof io) == 0;
+            ctx->h_frames[idx] = io;
         }
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frames + ctx->slot_base + f0, ctx->h_frames + ctx->slot_base + f0, nf * sizeof(frame_io), hipMemcpyHostToDevice,
-                                    ctx->stream));
+        if (!on_device) {
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frames + ctx->slot_base + f0, ctx->h_frames + ctx->slot_base + f0, nf * sizeof(frame_io), hipMemcpyHostToDevice,
+                                        ctx->stream));
+            for (int i = 0; i < nf; i++) ctx->dev_frames[(size_t)ctx->slot_base + f0 + i] = ctx->h_frames[(size_t)ctx->slot_base + f0 + i];
+        }
         const int grid = grid_for(ctx, var, (uint64_t)g.chunks * nf);
         const int waves = h2y_fused_threads(var) / 64; /* the fused kernels leave one min/max record per wave */
         /* frame groups (frame_walk in h2y_kernels.hip): as many as divide both the batch and the grid, up to 8 */
@@ -636,6 +645,7 @@ int reserve_batch(h2y_ctx *ctx, int n)
         if (ctx->h_fstats) HIP_TRY(ctx, hipHostFree(ctx->h_fstats));
         ctx->d_frames = nullptr; ctx->h_frames = nullptr; ctx->d_fstats = nullptr; ctx->h_fstats = nullptr;
         ctx->frames_cap = 0;
+        ctx->dev_frames.clear();
         size_t cap = (size_t)n < 64 ? 64 : (size_t)n;
         HIP_TRY(ctx, hipMalloc((void **)&ctx->d_frames, cap * sizeof(frame_io)));
         HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_frames, cap * sizeof(frame_io), hipHostMallocDefault));
@@ -1293,6 +1303,7 @@ int h2y_matrix_convert(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3
     io.tmp_cr = d_out444[2];
     ctx->h_frames[0] = io;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frames, ctx->h_frames, sizeof(frame_io), hipMemcpyHostToDevice, ctx->stream));
+    ctx->dev_frames.clear(); /* run_frames()'s record of what d_frames holds */
     const int grid = grid_for(ctx, var, g.chunks);
     rc = ensure(ctx, ctx->d_partial, ctx->partial_cap, (size_t)grid * (h2y_fused_threads(var) / 64) * 6 * sizeof(float));
     if (rc) return rc;

@@ -88,8 +88,8 @@ struct h2y_ctx {
      * of each XCD; the shares of the next launch follow the speeds seen (balance_update()). */
     unsigned long long *d_clock = nullptr;
     size_t clock_cap = 0;
-    float *d_xcd = nullptr, *h_xcd = nullptr; /* [8] */
-    bool bal_pending = false;                 /* h_xcd will hold the times of a launch dealt with bal_used_* */
+    int bal_slot = 0;                         /* the eight run times travel in the frame_stats entry after the batch's last */
+    bool bal_pending = false;                 /* h_fstats[bal_slot] will hold the times of a launch dealt with bal_used_* */
     uint32_t bal_used_mask = 0xFFu;
     double bal_used_extra = 0.0;              /* work of a fast block relative to a slow one, minus one, in that launch */
     bool bal_have = false;
@@ -424,7 +424,7 @@ void balance_update(h2y_ctx *ctx)
     ctx->bal_pending = false;
     double sp[8], mean = 0.0;
     for (int x = 0; x < 8; x++) {
-        const double t = ctx->h_xcd[x];
+        const double t = reinterpret_cast<const float *>(ctx->h_fstats + ctx->bal_slot)[x];
         if (!(t > 0.0)) return; /* grid smaller than a round of XCDs, or nothing measured */
         const double w = ((ctx->bal_used_mask >> x) & 1u) && ctx->bal_used_mask != 0xFFu ? 1.0 + ctx->bal_used_extra : 1.0;
         sp[x] = w / t;
@@ -552,10 +552,6 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
                 if (rc) return rc;
                 HIP_TRY(ctx, hipMemsetAsync(ctx->d_clock, 0, need, ctx->stream)); /* k_stats_final clears the finish entries from here on */
             }
-            if (!ctx->d_xcd) {
-                HIP_TRY(ctx, hipMalloc((void **)&ctx->d_xcd, 8 * sizeof(float)));
-                HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_xcd, 8 * sizeof(float), hipHostMallocDefault));
-            }
         }
         fused_args a;
         a.xcd_layout = xcd_layout ? 1u : 0u;
@@ -604,10 +600,11 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         fa.publish = nullptr;
         fa.block_clock = clocks ? ctx->d_clock : nullptr;
         fa.grid = grid;
-        fa.xcd_time = ctx->d_xcd;
+        static_assert(sizeof(frame_stats) >= 8 * sizeof(float), "the XCD run times ride in one frame_stats entry");
+        fa.xcd_time = reinterpret_cast<float *>(ctx->d_fstats + fstats_offset + n); /* the caller's copy of the statistics takes one entry more */
         HIP_TRY(ctx, h2y_launch_stats_final(nf, ctx->stream, fa));
         if (clocks) {
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->h_xcd, ctx->d_xcd, 8 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+            ctx->bal_slot = fstats_offset + n;
             ctx->bal_pending = true;
             ctx->bal_used_mask = fast_mask;
             ctx->bal_used_extra = extra;
@@ -833,8 +830,6 @@ void h2y_ctx_destroy(h2y_ctx *ctx)
     (void)hipFree(ctx->d_redo);
     (void)hipFree(ctx->d_low);
     (void)hipFree(ctx->d_clock);
-    (void)hipFree(ctx->d_xcd);
-    if (ctx->h_xcd) (void)hipHostFree(ctx->h_xcd);
     (void)hipFree(ctx->d_fstats);
     (void)hipHostFree(ctx->h_fstats);
     (void)hipFree(ctx->d_assumed);
@@ -916,7 +911,7 @@ int h2y_convert_batch_enqueue(h2y_ctx *ctx, const h2y_desc *d, int n_frames, con
     t1_begin_batch(ctx);
     rc = run_frames(ctx, d, ctx->p_frames.data(), n_frames, ctx->d_assumed, host_knows ? ctx->h_assumed : nullptr, check, 0, true);
     if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_fstats, ctx->d_fstats, n_frames * sizeof(frame_stats), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_fstats, ctx->d_fstats, ((size_t)n_frames + 1) * sizeof(frame_stats), hipMemcpyDeviceToHost, ctx->stream)); /* + the XCD run times */
     ctx->pending = true;
     ctx->p_desc = *d;
     ctx->p_n = n_frames;
@@ -1039,10 +1034,11 @@ int h2y_convert_frame(h2y_ctx *ctx, const h2y_desc *d, const void *const in_plan
     t1_begin_batch(ctx);
     rc = run_frames(ctx, d, &io, 1, ctx->d_assumed, host_knows ? ctx->h_assumed : nullptr, false, 0, true);
     if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_fstats, ctx->d_fstats, sizeof(frame_stats), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_fstats, ctx->d_fstats, 2 * sizeof(frame_stats), hipMemcpyDeviceToHost, ctx->stream)); /* + the XCD run times */
     HIP_TRY(ctx, hipMemcpyAsync(out_yuv, ctx->d_out, ob, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     t1_end_batch(ctx, d, ctx->h_fstats, 1);
+    balance_update(ctx);
     float ms = 0.f;
     for (int i = 0; i < ctx->n_ev; i++) {
         float t = 0.f;

@@ -84,6 +84,10 @@ struct frame_walk {
         f += (int)NG;
         set_firsts();
     }
+    /* first() / succ(): a block's chunks of a frame in order, and the step across the frame boundary.  The kernels
+     * used to walk them wave by wave; since waves take their tiles by ticket (wave_deal in h2y_kernels.hip) they
+     * use kA / kB / count_a() / count_b() directly, and these two remain as the definition tools/walk_check.cpp
+     * checks the closed form against. */
     /* this block's first chunk of the current frame */
     H2Y_FN bool first(uint32_t &k, bool &inB) const
     {

@@ -2,17 +2,26 @@
 """bench.py -- throughput of the hdr2yuv convert hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 A *step* is one pass of the hot path (pic_stats -> matrix_convert/PQ -> convert
 -> write_yuv arithmetic) over one batch of --frames synthetic frames per GPU,
 inputs already resident in HBM, outputs left in HBM in .yuv layout.  Workload =
-BASELINE.json configs[1]: 3840x2160 fp32 RGB -> PQ -> 12-bit BT.2020nc YCbCr
-4:2:0 (video range), chroma by the 2x2 box (the north_star's fused kernel);
-the FIR resampler (make.sh's example) is measured too and reported beside it.
+BASELINE.json configs[1] ("C2"): 3840x2160 fp32 RGB -> PQ -> 12-bit BT.2020nc
+YCbCr 4:2:0 (video range), chroma by the 2x2 box (the north_star's fused kernel).
+Beside it, at N = 1, shorter passes over the FIR resampler (make.sh's example, the
+CLI's default) and over configs[0] / [2] / [3] (C1, C3, C4), each with its own
+roofline fraction and md5 self-check.
 
-Frames shard by frame index: rank r owns frames [r*F, (r+1)*F) -- no data-path
-collective; RCCL carries one all-reduce of the counters (weak scaling).
+N > 1: one process per GPU.  Started under `python -m torch.distributed.run` the
+ranks come from the environment; started as plain `python bench.py --gpus N` this
+process launches that command itself BEFORE anything touches the GPU, and exits
+with its code.  Frames shard by frame index: rank r owns frames [r*F, (r+1)*F) --
+no data-path collective; RCCL carries one all-reduce / all-gather of the counters
+(weak scaling).  Fewer than N visible devices is an error, never a silent N = 1.
+
+The output bytes of frame 0 on rank 0 are the SURVEY 8c known-answer frame: their
+md5 is checked against tests/golden/known_md5.json after the timed loop
+("verified"); a mismatch fails the run.
 
 Prints ONE JSON line on rank 0.
 """
@@ -20,8 +29,11 @@ from __future__ import annotations
 
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,39 +41,105 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak (spec); ~5600 measured with a plain float4 copy
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak (spec); 6290 measured with a plain float4 copy (0.79)
 
 WORKLOADS = {
-    # name: (desc kwargs, algorithmic bytes per pixel: read input once + write output once)
+    # name: (desc kwargs, algorithmic bytes per pixel: read input once + write output once, text, known-answer stem)
     "C2": (dict(width=3840, height=2160, dst_depth=12, dst_matrix=9), 15.0,
-           "3840x2160 fp32 RGB -> PQ -> 12-bit BT.2020nc YCbCr 4:2:0"),
+           "3840x2160 fp32 RGB -> PQ -> 12-bit BT.2020nc YCbCr 4:2:0", "C2_4k_2020_12b"),
     "C3": (dict(width=3840, height=2160, dst_depth=16, dst_matrix=11, chroma=3), 18.0,
-           "3840x2160 fp32 XYZ -> PQ -> 16-bit YDzDx 4:4:4"),
+           "3840x2160 fp32 XYZ -> PQ -> 16-bit YDzDx 4:4:4", "C3_4k_ydzdx_16b_444"),
     "C4": (dict(width=7680, height=4320, sample=3, dst_depth=10, dst_matrix=9), 9.0,
-           "7680x4320 fp16 RGB -> PQ -> 10-bit BT.2020nc YCbCr 4:2:0"),
+           "7680x4320 fp16 RGB -> PQ -> 10-bit BT.2020nc YCbCr 4:2:0", "C4_8k_f16_2020_10b"),
     "C1": (dict(width=1920, height=1080, dst_depth=10, dst_matrix=1), 15.0,
-           "1920x1080 fp32 RGB -> PQ -> 10-bit BT.709 YCbCr 4:2:0"),
+           "1920x1080 fp32 RGB -> PQ -> 10-bit BT.709 YCbCr 4:2:0", "C1_1080p_709_10b"),
 }
+TRAFFIC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=10)  # the card clocks up during the first ~10 launches
-    ap.add_argument("--frames", type=int, default=64, help="frames per GPU per step (one launch covers them all; 64 x 124 MB = 8 GB of the 288)")
+    ap.add_argument("--frames", type=int, default=64, help="frames per GPU per step (64 x 124 MB = 8 GB of the 288)")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--resampler", default="box", choices=["box", "fir"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary (other resampler) measurement")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (other resampler, C1/C3/C4)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames for the CPU baseline sample (0 = auto ~15 s)")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (nccl = RCCL; gloo only to rehearse N > 1 on one GPU)")
+    ap.add_argument("--lib", default=None, help="load this build of libhdr2yuv_hip.so instead of the in-tree one (recorded in the JSON)")
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="h2y_ctx_set_option knobs (A/B timing), e.g. fir=twopass")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (nccl = RCCL; gloo only to rehearse N > 1)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
-    return ap.parse_args()
+    ap.add_argument("--rehearse", action="store_true",
+                    help="CPU rehearsal of the N-rank launch: ranks rendezvous (gloo), shard the frame indices and reduce made-up counters; "
+                         "no device, no conversion, nothing measured")
+    return ap.parse_args(argv)
+
+
+# ---------------------------------------------------------------------------------------------
+# N > 1 from a plain `python bench.py --gpus N`: this process only launches the ranks
+# ---------------------------------------------------------------------------------------------
+def launch_ranks(args) -> int:
+    """Parent of the N ranks.  Never makes a HIP call (torch.cuda.device_count() does not initialise the GPU
+    on this image); the ranks are fresh processes started by torch.distributed.run."""
+    n = args.gpus
+    if not args.rehearse:
+        import torch
+
+        have = torch.cuda.device_count()
+        need = 1 if args.share_gpu else n
+        if have < need:
+            print(f"[bench] --gpus {n} asked for but only {have} GPU(s) visible: refusing to measure fewer silently", file=sys.stderr)
+            return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ---------------------------------------------------------------------------------------------
+# synthetic input on the device (SURVEY 8c/8d generator; hdr2yuv_amd/synth.py is the host form)
+# ---------------------------------------------------------------------------------------------
+class DeviceSynth:
+    """uint32 s = 12345 + frame; per sample s = s*1664525 + 1013904223; v = (s >> 8) / 2^24; plane[0] = 0, plane[1] = 1.
+    Closed form of the LCG in 64-bit integers on the device (wrap-around multiplication keeps the low 32 bits exact)."""
+
+    def __init__(self, n_samples, dev):
+        import torch
+
+        a = torch.full((n_samples,), 1664525, dtype=torch.int64, device=dev)
+        self.ai = torch.cumprod(a, 0) & 0xFFFFFFFF                                # a^(i+1) mod 2^32
+        del a
+        geo = torch.cat([torch.ones(1, dtype=torch.int64, device=dev), self.ai[:-1]])
+        self.geo_c = ((torch.cumsum(geo, 0) & 0xFFFFFFFF) * 1013904223) & 0xFFFFFFFF  # c * sum_{j<=i} a^j
+        del geo
+
+    def frame(self, width, height, k, f16):
+        import torch
+
+        n = width * height
+        s = (self.ai * (12345 + k) + self.geo_c) & 0xFFFFFFFF
+        v = (s >> 8).to(torch.float32) * (1.0 / 16777216.0)
+        planes = []
+        for c in range(3):
+            p = v[c * n:(c + 1) * n].clone()
+            if f16:
+                p = p.to(torch.float16)
+            p[0], p[1] = 0.0, 1.0
+            planes.append(p.view(torch.int16) if f16 else p)
+        return planes
 
 
 def run_steps(ctx, d, n_frames, ins, outs, steps, warmup, barrier):
-    """W untimed + K timed steps. Returns (seconds for K steps, mean kernel ms per step, redone frames)."""
+    """W untimed + K timed steps. Returns (seconds for K steps, mean kernel ms per step, redone frames, launches per step)."""
     import torch
 
     for _ in range(warmup):
@@ -72,23 +150,22 @@ def run_steps(ctx, d, n_frames, ins, outs, steps, warmup, barrier):
     t0 = time.perf_counter()
     kms = 0.0
     redone = 0
+    launches = 0
     for _ in range(steps):
         ctx.convert_batch_enqueue_raw(d, n_frames, ins, outs)
         redone += ctx.batch_finish()
-        ms, _n = ctx.last_kernel_ms()
+        ms, launches = ctx.last_kernel_ms()
         kms += ms
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
-    return t1 - t0, kms / max(steps, 1), redone
+    return t1 - t0, kms / max(steps, 1), redone, launches
 
 
 def cpu_baseline(desc_kw, resampler, n_frames_hint):
     """The reference CPU path timed on this box's host cores, single thread (the
     reference is single-threaded): oracle/_ref (the reference's own object code)
     when that prebuilt library travelled with the repo, else our C restatement."""
-    import numpy as np  # noqa: F401
-
     from hdr2yuv_amd.synth import synth_frame
     from oracle import binding as ob
 
@@ -125,10 +202,8 @@ def cpu_baseline(desc_kw, resampler, n_frames_hint):
 def cpu_baseline_parallel(desc_kw, resampler, frames_each=2):
     """Frame-parallel run of the same CPU path: one single-threaded process per host core, each converting
     `frames_each` frames (SURVEY 8d asks for both figures; the reference itself is one process per frame)."""
-    import subprocess
-
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores, int(os.environ.get("H2Y_CPU_WORKERS", "16"))))  # a one-GPU box's CPU share is 16 cores, whatever the affinity mask says
+    cores = max(1, min(cores, 16))  # a one-GPU box's CPU share is 16 cores, whatever the affinity mask says
     kw = dict(desc_kw)
     if kw.get("sample") == 3 or kw.get("chroma", 1) != 1:
         return None  # the helper script covers the fp32 4:2:0 workloads
@@ -148,21 +223,78 @@ def cpu_baseline_parallel(desc_kw, resampler, frames_each=2):
             "sample": f"{cores} processes x {frames_each} frame(s), {dt:.1f} s wall including process start-up"}
 
 
-def main():
+def known_md5(stem, is420, resampler):
+    name = stem if not is420 else f"{stem}_{resampler}"
+    with open(os.path.join(ROOT, "tests", "golden", "known_md5.json")) as f:
+        case = json.load(f)["cases"].get(name)
+    return name, (case or {}).get("md5")
+
+
+def rehearse(args, world, rank):
+    """--rehearse: what the ranks do around the measurement, with nothing measured (CPU, gloo)."""
+    import torch
+    import torch.distributed as dist
+
+    from hdr2yuv_amd.shard import frames_for_rank
+
+    if world > 1:
+        dist.init_process_group(backend="gloo")
+    F = args.frames
+    mine = frames_for_rank(world * F, rank, world)
+    desc_kw = WORKLOADS[args.workload][0]
+    px = float(len(mine)) * desc_kw["width"] * desc_kw["height"] * args.steps
+    secs = 1.0 + 0.25 * rank  # made up: the slowest rank sets the job's time
+    mine_t = torch.tensor([secs, px, float(mine.start), float(mine.stop)], dtype=torch.float64)
+    allr = [torch.zeros_like(mine_t) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(allr, mine_t)
+    else:
+        allr = [mine_t]
+    tmax = max(float(t[0]) for t in allr)
+    total = sum(float(t[1]) for t in allr)
+    out = {"rehearsal": True, "metric": "none (launch rehearsal: nothing measured)", "value": None, "n_gpus": world, "steps": args.steps,
+           "warmup": args.warmup, "backend": "gloo", "pixels_total": total, "seconds_max": tmax,
+           "per_rank": [{"rank": r, "frames": [int(t[2]), int(t[3])], "seconds": float(t[0])} for r, t in enumerate(allr)]}
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    return 0
+
+
+def main() -> int:
     args = parse()
-    import numpy as np
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and env_world is None:
+        return launch_ranks(args)  # parent: no GPU call before or after
+    world = int(env_world or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a different N than asked for", file=sys.stderr)
+        return 2
+    if args.rehearse:
+        return rehearse(args, world, rank)
+
     import torch
     import torch.distributed as dist
 
     import hdr2yuv_amd as h
+    from hdr2yuv_amd import api as h_api
     from hdr2yuv_amd.shard import frames_for_rank
-    from hdr2yuv_amd.synth import synth_frame
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.lib:
+        h_api.set_library_path(args.lib)
     if args.share_gpu:
+        if args.backend != "gloo":
+            print("[bench] --share-gpu needs --backend gloo", file=sys.stderr)
+            return 2
         local_rank = 0
+    elif torch.cuda.device_count() <= local_rank:
+        print(f"[bench] rank {rank}: no GPU {local_rank} (visible: {torch.cuda.device_count()})", file=sys.stderr)
+        return 2
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
@@ -173,38 +305,92 @@ def main():
     else:
         torch.cuda.set_device(0)
         local_rank = 0
-    n_gpus = world
-    if rank == 0 and args.gpus != world:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using {world}", file=sys.stderr)
 
     def barrier():
         if world > 1:
             dist.barrier()
 
-    desc_kw, bytes_per_px, wl_name = WORKLOADS[args.workload]
-    is420 = desc_kw.get("chroma", 1) == 1
-    F = args.frames
-    w, hh = desc_kw["width"], desc_kw["height"]
-    f16 = desc_kw.get("sample") == 3
     dev = torch.device("cuda", local_rank)
-
-    # ---- synthetic input, resident in HBM before any timed region --------
-    frames_in = []
-    for k in frames_for_rank(world * F, rank, world):  # this rank's contiguous block of the global frame sequence
-        planes = synth_frame(w, hh, k, f16=f16)
-        frames_in.append([torch.from_numpy(p.view(np.int16) if f16 else p).to(dev) for p in planes])
+    red_dev = dev if args.backend == "nccl" else torch.device("cpu")
     ctx = h.Context(local_rank)
+    for kv in args.option:
+        name, _, value = kv.partition("=")
+        ctx.set_option(name, value)
+    lib_path = h.library_path()
+    with open(lib_path, "rb") as f:
+        lib_sha = hashlib.sha256(f.read()).hexdigest()
 
-    def make_io(resampler):
+    synth_cache = {}
+
+    def device_frames(desc_kw, indices):
+        w, hh = desc_kw["width"], desc_kw["height"]
+        f16 = desc_kw.get("sample") == 3
+        key = 3 * w * hh
+        if key not in synth_cache:
+            synth_cache.clear()
+            synth_cache[key] = DeviceSynth(key, dev)
+        return [synth_cache[key].frame(w, hh, k, f16) for k in indices]
+
+    def measure(wl, resampler, frames_in, F, steps, warmup):
+        """One timed pass of workload `wl` over F frames per step (frames_in may hold fewer DISTINCT inputs: they repeat;
+        every frame has its own output).  Returns a dict of figures; all ranks call it together."""
+        desc_kw, bytes_per_px, wl_name, stem = WORKLOADS[wl]
+        is420 = desc_kw.get("chroma", 1) == 1
+        w, hh = desc_kw["width"], desc_kw["height"]
         d = h.make_desc(**dict(desc_kw, resampler=1 if resampler == "fir" else 0))
         nb = h.frame_bytes(d)
         outs_t = [torch.empty(nb // 2, dtype=torch.int16, device=dev) for _ in range(F)]
-        ins = (C.c_void_p * (3 * F))(*[t.data_ptr() for fr in frames_in for t in fr])
+        ins = (C.c_void_p * (3 * F))(*[t.data_ptr() for i in range(F) for t in frames_in[i % len(frames_in)]])
         outs = (C.c_void_p * F)(*[t.data_ptr() for t in outs_t])
-        return d, ins, outs, outs_t
+        secs, kernel_ms, redone, launches = run_steps(ctx, d, F, ins, outs, steps, warmup, barrier)
+        mine = torch.tensor([secs, float(F) * w * hh * steps], dtype=torch.float64, device=red_dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(allr, mine)  # RCCL over xGMI: two doubles per rank
+        else:
+            allr = [mine]
+        tmax = max(float(t[0]) for t in allr)
+        total_px = sum(float(t[1]) for t in allr)
+        variant = ctx.last_kernel_variant()
+        kernel = ctx.last_kernel_name() + ("+k_fir420" if "+k_fir420" in variant else "")
+        # self-check: rank 0's frame 0 is the SURVEY 8c known-answer frame of this workload
+        verified, vname, got_md5 = None, None, None
+        if rank == 0:
+            vname, want = known_md5(stem, is420, resampler)
+            if want:
+                got_md5 = hashlib.md5(outs_t[0].cpu().numpy().tobytes()).hexdigest()
+                verified = got_md5 == want
+        del outs_t
+        alg_bytes = bytes_per_px * w * hh * F  # per step
+        ach_kernel = alg_bytes / (kernel_ms / 1e3) / 1e9 if kernel_ms > 0 else 0.0
+        ach_wall = alg_bytes / (secs / steps) / 1e9
+        return dict(workload=wl, text=wl_name, resampler=resampler if is420 else "none", is420=is420, secs=tmax, pixels=total_px, steps=steps,
+                    per_rank=[float(t[1]) / float(t[0]) / 1e6 for t in allr], kernel_ms=kernel_ms, launches=launches, redone=redone,
+                    kernel=kernel, variant=variant, verified=verified, verify_case=vname, md5=got_md5, alg_bytes=alg_bytes,
+                    ach_kernel=ach_kernel, ach_wall=ach_wall, w=w, h=hh, frames=F)
 
-    # a plain device-to-device copy of 1 GiB on this very box (30 times), as the practical HBM ceiling beside the
-    # 8 TB/s spec; measured first, while the inputs are fresh in HBM and before the W warm-up steps
+    def roofline_of(r, traffic=None, traffic_source=None):
+        """Dominant kernel of the pass.  Box / 4:4:4 and the fused FIR path run ONE kernel per launch: `achieved` is its
+        algorithmic bytes over its HIP-event time on its own stream.  The two-pass FIR form (fused kernel + k_fir420 on a
+        second stream) has no single dominant kernel: its figure is over the wall time of a step and says so."""
+        two_pass = r["kernel"].endswith("+k_fir420")
+        ach = r["ach_wall"] if two_pass else r["ach_kernel"]
+        out = {"bound": "hbm", "kernel": r["kernel"], "variant": r["variant"], "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+               "timed_by": "wall time of a step (two kernels on two streams)" if two_pass else "HIP events around the kernel, on its stream",
+               "algorithmic_bytes_per_launch": r["alg_bytes"] / max(r["launches"], 1), "launches_per_step": r["launches"],
+               "kernel_ms_per_step": round(r["kernel_ms"], 4)}
+        return out
+
+    # ---- main measurement -----------------------------------------------------------------
+    desc_kw, bytes_per_px, wl_name, stem = WORKLOADS[args.workload]
+    is420 = desc_kw.get("chroma", 1) == 1
+    F = args.frames
+    w, hh = desc_kw["width"], desc_kw["height"]
+    frames_in = device_frames(desc_kw, frames_for_rank(world * F, rank, world))  # this rank's contiguous block of the global frame sequence
+    torch.cuda.synchronize()
+
+    # a plain device-to-device copy of 1 GiB on this very box (30 times): context only, it swings by +-10 % between runs
     copy_gbs = None
     try:
         src_t = torch.empty(1 << 28, dtype=torch.float32, device=dev)
@@ -221,21 +407,8 @@ def main():
         del src_t, dst_t
     except Exception:
         copy_gbs = None
-    results = {}
-    order = [args.resampler] + ([] if (args.no_extra or not is420) else [r for r in ("box", "fir") if r != args.resampler])
-    for res in order:
-        d, ins, outs, outs_t = make_io(res)
-        secs, kernel_ms, redone = run_steps(ctx, d, F, ins, outs, args.steps, args.warmup, barrier)
-        t = torch.tensor([secs], dtype=torch.float64, device=dev)
-        px = torch.tensor([float(F) * w * hh * args.steps], dtype=torch.float64, device=dev)
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)   # max over ranks
-            dist.all_reduce(px, op=dist.ReduceOp.SUM)  # pixels all ranks processed (RCCL over xGMI)
-        results[res] = dict(secs=float(t.item()), pixels=float(px.item()), kernel_ms=kernel_ms, redone=redone, kernel=ctx.last_kernel_name(),
-                            checksum=int(outs_t[0][:4096].to(torch.int64).sum().item()))
-        del outs_t
 
-    main_r = results[args.resampler]
+    main_r = measure(args.workload, args.resampler, frames_in, F, args.steps, args.warmup)
     value = main_r["pixels"] / main_r["secs"] / 1e6
     ms_per_step = main_r["secs"] / args.steps * 1e3
 
@@ -243,7 +416,7 @@ def main():
         "metric": "Mpixels/s, 4K RGB->YUV420 PQ convert path (in-memory, HBM-resident)",
         "value": round(value, 1),
         "unit": "Mpixels/s",
-        "n_gpus": n_gpus,
+        "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
@@ -259,39 +432,65 @@ def main():
             "resampler": args.resampler if is420 else "none",
         },
         "frames_per_s": round(value * 1e6 / (w * hh), 1),
+        "per_rank_mpixels_s": [round(v, 1) for v in main_r["per_rank"]],
+        "verified": main_r["verified"],
+        "verify": {"case": main_r["verify_case"], "md5": main_r["md5"], "what": "md5 of rank 0's output frame 0 after the timed loop vs tests/golden/known_md5.json"},
+        "library": {"path": os.path.relpath(lib_path, ROOT) if lib_path.startswith(ROOT) else lib_path, "sha256": lib_sha},
+        "options": args.option,
     }
-    # ---- roofline of the dominant kernel (k_fused), HIP-event timed on its stream
-    alg_bytes = bytes_per_px * w * hh * F  # per launch: one launch covers the F frames of a step (box / 4:4:4)
-    kernel_s = main_r["kernel_ms"] / 1e3
-    launches = 1 if (args.resampler == "box" or not is420) else (F + 31) // 32
-    ach = alg_bytes / kernel_s / 1e9 if kernel_s > 0 else 0.0
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    traffic, traffic_source = None, None
+    tpath = os.path.join(ROOT, TRAFFIC_FILE)
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            traffic = tj.get(f"{args.workload}_{args.resampler}_F{F}", {}).get("hbm_bytes_per_launch")
+            ent = tj.get(f"{args.workload}_{args.resampler}_F{F}")
+            if ent and ent.get("library_sha256") == lib_sha:
+                traffic = ent.get("hbm_bytes_per_launch")
+                traffic_source = f"{TRAFFIC_FILE} (rocprofv3 --pmc passes of this very library build; static, not this run)"
+            elif ent:
+                traffic_source = f"{TRAFFIC_FILE} holds counters of another library build: not quoted"
         except Exception:
             traffic = None
-    out["roofline"] = {
-        "bound": "hbm",
-        "kernel": main_r["kernel"],
-        "achieved": round(ach, 1),
-        "peak": HBM_PEAK_GBS,
-        "unit": "GB/s",
-        "frac": round(ach / HBM_PEAK_GBS, 4),
-        "traffic": traffic,
-        "algorithmic_bytes_per_launch": alg_bytes / launches,
-        "launches_per_step": launches,
-        "kernel_ms_per_step": round(main_r["kernel_ms"], 4),
-        "device_copy_gbs": None if copy_gbs is None else round(copy_gbs, 1),
-        "frac_of_device_copy": None if not copy_gbs else round(ach / copy_gbs, 4),
-    }
-    for res, r in results.items():
-        if res != args.resampler:
-            out[f"{res}_value"] = round(r["pixels"] / r["secs"] / 1e6, 1)
-            out[f"{res}_ms_per_step"] = round(r["secs"] / args.steps * 1e3, 4)
+    out["roofline"] = roofline_of(main_r, traffic, traffic_source)
+    out["roofline"]["device_copy_gbs"] = None if copy_gbs is None else round(copy_gbs, 1)
     out["frames_redone"] = main_r["redone"]
+    failed = main_r["verified"] is False
+
+    # ---- secondary passes (N = 1): the other resampler and the other BASELINE configs -------
+    if world == 1 and not args.no_extra:
+        others = {}
+        sec_steps, sec_warm = max(5, args.steps // 2), max(3, args.warmup // 2)
+        plan = []
+        if is420:
+            plan.append((args.workload, "fir" if args.resampler == "box" else "box", F))
+        for wl, nf in (("C3", 64), ("C1", 64), ("C4", 16)):
+            if wl != args.workload:
+                plan.append((wl, "box", nf))
+        if args.workload != "C4":
+            plan.append(("C4", "fir", 16))
+        for wl, res, nf in plan:
+            kw2 = WORKLOADS[wl][0]
+            same_input = (kw2["width"], kw2["height"], kw2.get("sample", 2)) == (w, hh, desc_kw.get("sample", 2))
+            if same_input:
+                fin = frames_in  # C3 reads the very frames C2 reads (fp32 4K planes)
+            else:
+                ndist = nf if kw2["width"] * kw2["height"] <= 3840 * 2160 else 4  # 8K: four distinct frames, each read four times per step
+                fin = device_frames(kw2, range(ndist))
+            r = measure(wl, res, fin, nf, sec_steps, sec_warm)
+            key = wl if WORKLOADS[wl][0].get("chroma", 1) != 1 else f"{wl}_{res}"
+            rf = roofline_of(r)
+            others[key] = {"value": round(r["pixels"] / r["secs"] / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(r["secs"] / r["steps"] * 1e3, 4),
+                           "frames_per_step": nf, "distinct_input_frames": len(fin), "steps": r["steps"], "kernel": r["kernel"], "variant": r["variant"],
+                           "frac": rf["frac"], "achieved_gbs": rf["achieved"], "timed_by": rf["timed_by"], "bytes_per_pixel": WORKLOADS[wl][1],
+                           "verified": r["verified"], "verify_case": r["verify_case"], "workload": r["text"] + (f", chroma {res}" if r["is420"] else "")}
+            failed = failed or r["verified"] is False
+            if fin is not frames_in:
+                del fin
+                torch.cuda.empty_cache()
+        out["others"] = others
+        if is420 and args.resampler == "box" and f"{args.workload}_fir" in others:  # round-1 field names, kept
+            out["fir_value"] = others[f"{args.workload}_fir"]["value"]
+            out["fir_ms_per_step"] = others[f"{args.workload}_fir"]["ms_per_step"]
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -307,7 +506,10 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+        if failed:
+            print("[bench] output bytes do not match the known answer: the figures above are void", file=sys.stderr)
+    return 1 if failed else 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -30,4 +30,5 @@ from .api import (  # noqa: F401
     library_path,
     load_library,
     make_desc,
+    set_library_path,
 )

@@ -27,8 +27,8 @@ H2Y_OK, H2Y_EINVAL, H2Y_EUNSUPPORTED, H2Y_EHIP, H2Y_ENOMEM = 0, 1, 2, 3, 4
 EXPORTS = [
     "h2y_abi_version", "h2y_frame_bytes", "h2y_plane_bytes", "h2y_desc_check", "h2y_ctx_create", "h2y_ctx_destroy",
     "h2y_last_error", "h2y_ctx_set_stream", "h2y_convert_frame", "h2y_convert_batch", "h2y_convert_batch_enqueue",
-    "h2y_batch_finish", "h2y_pic_stats", "h2y_matrix_convert", "h2y_subsample_420", "h2y_last_kernel_ms", "h2y_last_kernel_name",
-    "h2y_matrix_inverse", "h2y_stream_open", "h2y_stream_input", "h2y_stream_submit", "h2y_stream_output", "h2y_stream_close",
+    "h2y_batch_finish", "h2y_pic_stats", "h2y_matrix_convert", "h2y_subsample_420", "h2y_last_kernel_ms", "h2y_last_kernel_name", "h2y_last_kernel_variant",
+    "h2y_matrix_inverse", "h2y_ctx_set_option", "h2y_stream_open", "h2y_stream_input", "h2y_stream_submit", "h2y_stream_output", "h2y_stream_close",
 ]
 
 
@@ -73,9 +73,20 @@ def make_desc(width, height, *, sample=SAMPLE_F32, src_depth=32, dst_depth=10, s
     return d
 
 
+_LIB_PATH = os.path.join(_HERE, "libhdr2yuv_hip.so")
+
+
 def library_path() -> str:
-    # H2Y_LIB: tuning experiments load an alternative build of the same library
-    return os.environ.get("H2Y_LIB") or os.path.join(_HERE, "libhdr2yuv_hip.so")
+    return _LIB_PATH
+
+
+def set_library_path(path: str) -> None:
+    """Load another build of the same library (tuning experiments: bench.py --lib, tools/).  Explicit, never from the
+    environment; must be called before the first load_library()."""
+    global _LIB_PATH
+    if _LIB is not None:
+        raise RuntimeError("the library is already loaded")
+    _LIB_PATH = os.path.abspath(path)
 
 
 def build_library(force: bool = False) -> str:
@@ -118,6 +129,8 @@ def load_library():
     L.h2y_ctx_destroy.argtypes = [C.c_void_p]
     L.h2y_last_error.restype = C.c_char_p
     L.h2y_last_error.argtypes = [C.c_void_p]
+    L.h2y_ctx_set_option.restype = C.c_int
+    L.h2y_ctx_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
     L.h2y_ctx_set_stream.restype = C.c_int
     L.h2y_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.h2y_convert_frame.restype = C.c_int
@@ -149,6 +162,8 @@ def load_library():
     L.h2y_stream_close.argtypes = [C.c_void_p]
     L.h2y_last_kernel_name.restype = C.c_char_p
     L.h2y_last_kernel_name.argtypes = [C.c_void_p]
+    L.h2y_last_kernel_variant.restype = C.c_char_p
+    L.h2y_last_kernel_variant.argtypes = [C.c_void_p]
     L.h2y_last_kernel_ms.restype = C.c_int
     L.h2y_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)]
     _LIB = L
@@ -195,6 +210,10 @@ class Context:
     def _check(self, rc):
         if rc != H2Y_OK:
             raise H2YError(rc, (self.lib.h2y_last_error(self.h) or b"").decode())
+
+    def set_option(self, name: str, value) -> None:
+        """h2y_ctx_set_option: "t1", "groups", "cols8", "balance", "fir" (tuning / test knobs; output bytes never change)."""
+        self._check(self.lib.h2y_ctx_set_option(self.h, name.encode(), str(value).encode()))
 
     def set_stream(self, hip_stream_ptr: int | None):
         self._check(self.lib.h2y_ctx_set_stream(self.h, C.c_void_p(hip_stream_ptr or 0)))
@@ -305,3 +324,6 @@ class Context:
 
     def last_kernel_name(self) -> str:
         return (self.lib.h2y_last_kernel_name(self.h) or b"").decode()
+
+    def last_kernel_variant(self) -> str:
+        return (self.lib.h2y_last_kernel_variant(self.h) or b"").decode()

@@ -98,6 +98,14 @@ struct h2y_ctx {
     double bal_rho = 1.0;                     /* how much more work a fast block gets than a slow one */
     int t1_skip = 0, t1_skip_len = 0;
     bool cur_skip_t1 = false;
+    /* h2y_ctx_set_option(): tuning / test knobs, per context (nothing is read from the environment) */
+    bool opt_t1 = true;        /* "t1": binary32 first tier on */
+    int opt_groups = 8;        /* "groups": at most this many frame groups (power of two; 1 = off) */
+    bool opt_cols8 = true;     /* "cols8": 8-column tiles for half input where the planes allow */
+    int opt_bal_mode = 0;      /* "balance": 0 adaptive, 1 off, 2 fixed */
+    uint32_t opt_bal_mask = 0xFFu;
+    double opt_bal_rho = 1.0;
+    int opt_fir = 0;           /* "fir": 0 auto, 1 two-pass (4:4:4 scratch + k_fir420), 2 fused single pass where it applies */
     bool last_was_t1 = false;
     size_t partial_cap = 0;
     frame_stats *d_fstats = nullptr, *h_fstats = nullptr;
@@ -142,6 +150,7 @@ struct h2y_ctx {
     int n_ev = 0;
     float last_ms = 0.f;
     const char *last_name = "";
+    std::string last_variant; /* last_name with its template arguments and launch shape, e.g. "k_fused_t1<F32,420BOX,YCBCR,PQ_IDENT> groups=8 xcd=1" */
     int last_launches = 0;
     std::string err;
 };
@@ -309,35 +318,9 @@ void t1_end_batch(h2y_ctx *ctx, const h2y_desc *d, const frame_stats *fs, int n)
     } else ctx->t1_skip_len = 0;
 }
 
-/* H2Y_GROUPS=n in the environment caps the number of frame groups (A/B timing; 1 = off) */
-int max_groups()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("H2Y_GROUPS");
-        v = e ? atoi(e) : 8;
-        if (v < 1) v = 1;
-        int p = 1;
-        while (2 * p <= v && p < 64) p *= 2; /* power of two */
-        v = p;
-    }
-    return v;
-}
-
 /* known: the floor/ceiling the kernels will assume, when the HOST knows them (hint or
  * override); NULL when they only exist in device memory (stats pre-pass). */
-/* H2Y_T1=0 in the environment keeps the binary32 first tier off (A/B timing) */
-bool t1_enabled()
-{
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("H2Y_T1");
-        v = (e && e[0] == '0') ? 0 : 1;
-    }
-    return v == 1;
-}
-
-fused_variant pick_variant(const h2y_desc *d, const pix_params &pp, int out_kind, const assumed_stats *known, t1_sens *sn)
+fused_variant pick_variant(const h2y_ctx *ctx, const h2y_desc *d, const pix_params &pp, int out_kind, const assumed_stats *known, t1_sens *sn)
 {
     memset(sn, 0, sizeof *sn);
     fused_variant v;
@@ -355,7 +338,7 @@ fused_variant pick_variant(const h2y_desc *d, const pix_params &pp, int out_kind
         v.pipe = ident ? 1 : 2; /* 2 is always valid: (x - 0) / 1 == x exactly */
         if (pp.convert_transfer == 2) v.pipe = 0; /* generic transfer pair: runtime kernel, careful tier */
         /* binary32 first tier where few pixels would fall through it (moderate bit depths) */
-        if ((v.pipe == 1 || v.pipe == 2) && v.in_kind != H2Y_IN_U16 && (d->height & 1) == 0 && t1_enabled() && t1_bounds(pp, sn)) v.pipe += 3;
+        if ((v.pipe == 1 || v.pipe == 2) && v.in_kind != H2Y_IN_U16 && (d->height & 1) == 0 && ctx->opt_t1 && t1_bounds(pp, sn)) v.pipe += 3;
         /* half input with the identity normalisation: the whole transfer is a 64 KB table */
         if (ident && v.in_kind == H2Y_IN_F16 && v.even_h && (pp.mode == H2Y_MODE_YCBCR || pp.mode == H2Y_MODE_YDZDX)) v.pipe = 3;
     }
@@ -370,38 +353,13 @@ int out_kind_of(const h2y_desc *d)
     return d->chroma_resampler_type == 0 ? H2Y_OUT_420BOX : H2Y_OUT_444TMP;
 }
 
-/* H2Y_BALANCE=off keeps the rounds unweighted; H2Y_BALANCE=<mask>,<rho> (e.g. 0x55,1.07) fixes the weights (tests, A/B timing) */
-int balance_env(uint32_t *mask, double *rho)
-{
-    int mode = 0; /* 0 adaptive, 1 off, 2 fixed; read at every launch (the tests change it) */
-    uint32_t m = 0xFFu;
-    double r = 1.0;
-    const char *e = getenv("H2Y_BALANCE");
-    if (e && !strcmp(e, "off")) mode = 1;
-    else if (e) {
-        char *end = nullptr;
-        const unsigned long mm = strtoul(e, &end, 0);
-        if (end && *end == ',' && (mm & 0xFFu) && (mm & 0xFFu) != 0xFFu) {
-            m = (uint32_t)(mm & 0xFFu);
-            r = atof(end + 1);
-            if (r > 1.0) mode = 2;
-        }
-    }
-    *mask = m;
-    *rho = r;
-    return mode;
-}
-
 /* the split of a frame's chunks for this launch: chunks [0, *chunks_a) round all blocks, the rest round the fast ones */
 void balance_for_launch(const h2y_ctx *ctx, uint32_t cpf, uint32_t *mask, uint32_t *chunks_a, double *extra)
 {
     uint32_t m = ctx->bal_mask;
     double rho = ctx->bal_rho;
-    uint32_t em;
-    double er;
-    const int mode = balance_env(&em, &er);
-    if (mode == 1) { m = 0xFFu; rho = 1.0; }
-    if (mode == 2) { m = em; rho = er; }
+    if (ctx->opt_bal_mode == 1) { m = 0xFFu; rho = 1.0; }
+    if (ctx->opt_bal_mode == 2) { m = ctx->opt_bal_mask; rho = ctx->opt_bal_rho; }
     *mask = 0xFFu;
     *chunks_a = cpf;
     *extra = 0.0;
@@ -462,15 +420,13 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
     derive_params(d, &pp, false);
     const int out_kind = out_kind_of(d);
     t1_sens sn;
-    fused_variant var = pick_variant(d, pp, out_kind, known, &sn);
+    fused_variant var = pick_variant(ctx, d, pp, out_kind, known, &sn);
     /* k_fused_t1's redo list numbers tiles as frame * tiles + tile in 32 bits */
     if ((var.pipe == 4 || var.pipe == 5) && (uint64_t)n * make_geom(d, h2y_fused_threads(var)).tiles >= 0xFFFFFFFFull) var.pipe -= 3;
     if ((var.pipe == 4 || var.pipe == 5) && ctx->cur_skip_t1) var.pipe -= 3; /* dense zeros lately: binary64 tier for now */
     ctx->last_was_t1 = var.pipe == 4 || var.pipe == 5;
     if (var.pipe == 3 && d->width % 8 == 0) { /* half input through the table: 8-column tiles when every plane allows 16-byte accesses */
-        bool ok = true;
-        const char *e = getenv("H2Y_COLS8"); /* =0: the general 4-column form (A/B timing) */
-        if (e && e[0] == '0') ok = false;
+        bool ok = ctx->opt_cols8;
         for (int i = 0; i < n && ok; i++) {
             for (int c = 0; c < 3; c++) ok = ok && (reinterpret_cast<uintptr_t>(frames[i].in[c]) & 15u) == 0;
             ok = ok && (reinterpret_cast<uintptr_t>(frames[i].out) & 15u) == 0;
@@ -517,7 +473,7 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         /* frame groups (frame_walk in h2y_kernels.hip): as many as divide both the batch and the grid, up to 8 */
         int groups = 1;
         if (h2y_fused_grouped(var))
-            for (int ng = max_groups(); ng > 1; ng >>= 1)
+            for (int ng = ctx->opt_groups; ng > 1; ng >>= 1)
                 if (nf % ng == 0 && grid % ng == 0) {
                     groups = ng;
                     break;
@@ -581,6 +537,13 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         if (ev) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->n_ev][0], ctx->stream));
             ctx->last_name = h2y_fused_name(var);
+            static const char *const kIn[] = {"F32", "F16", "U16"}, *const kOut[] = {"420BOX", "444", "444TMP"};
+            static const char *const kPipe[] = {"RUNTIME", "PQ_IDENT", "PQ_NORM", "LUT16", "PQ_IDENT", "PQ_NORM", "NONE"};
+            const char *mode = var.mode == H2Y_MODE_YCBCR ? "YCBCR" : var.mode == H2Y_MODE_YDZDX ? "YDZDX" : var.mode == H2Y_MODE_IDENTITY ? "IDENTITY" : "YPQRS";
+            char buf[192];
+            snprintf(buf, sizeof buf, "%s<%s,%s,%s,%s%s>%s groups=%d xcd=%d", ctx->last_name, kIn[var.in_kind], kOut[var.out_kind], mode,
+                     kPipe[var.pipe], var.cols8 ? ",COLS8" : "", out_kind == H2Y_OUT_444TMP ? "+k_fir420" : "", groups, xcd_layout ? 1 : 0);
+            ctx->last_variant = buf;
         }
         HIP_TRY(ctx, h2y_launch_fused(var, grid, ctx->stream, a));
         if (ev) {
@@ -758,18 +721,11 @@ size_t h2y_plane_bytes(const h2y_desc *d)
 
 const char *h2y_last_error(const h2y_ctx *ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 
-int h2y_ctx_create(int device, h2y_ctx **out)
+/* everything h2y_ctx_create() allocates; on a failure the caller destroys the half-built context */
+static int ctx_init(h2y_ctx *ctx, int device)
 {
-    if (!out) return fail(nullptr, H2Y_EINVAL, "null out pointer");
-    *out = nullptr;
-    int ndev = 0;
-    hipError_t e = hipGetDeviceCount(&ndev);
-    if (e != hipSuccess || ndev < 1)
-        return fail(nullptr, H2Y_EHIP, "no HIP device (%s): this library has no CPU path", hipGetErrorString(e));
-    if (device < 0 || device >= ndev) return fail(nullptr, H2Y_EINVAL, "device %d out of range (have %d)", device, ndev);
-    h2y_ctx *ctx = new (std::nothrow) h2y_ctx();
-    if (!ctx) return fail(nullptr, H2Y_ENOMEM, "out of host memory");
     ctx->device = device;
+    for (int i = 0; i < kMaxEvents; i++) ctx->ev[i][0] = ctx->ev[i][1] = nullptr;
     HIP_TRY(ctx, hipSetDevice(device));
     hipDeviceProp_t prop;
     HIP_TRY(ctx, hipGetDeviceProperties(&prop, device));
@@ -790,9 +746,8 @@ int h2y_ctx_create(int device, h2y_ctx **out)
         std::vector<pq_recA> A(H2Y_PQ_NREC);
         std::vector<pq_recB> B(H2Y_PQ_NREC);
         pq_build_table(A.data(), B.data());
-        char *t = nullptr;
-        HIP_TRY(ctx, hipMalloc((void **)&t, H2Y_PQ_TABLE_BYTES));
-        ctx->d_table = t;
+        HIP_TRY(ctx, hipMalloc(&ctx->d_table, H2Y_PQ_TABLE_BYTES));
+        char *t = static_cast<char *>(ctx->d_table);
         HIP_TRY(ctx, hipMemcpy(t, A.data(), H2Y_PQ_NREC * 16, hipMemcpyHostToDevice));
         HIP_TRY(ctx, hipMemcpy(t + H2Y_PQ_NREC * 16, B.data(), H2Y_PQ_NREC * 16, hipMemcpyHostToDevice));
         std::vector<pq_rec1> T1(H2Y_T1_NREC);
@@ -805,9 +760,65 @@ int h2y_ctx_create(int device, h2y_ctx **out)
     }
     HIP_TRY(ctx, hipMalloc((void **)&ctx->d_assumed, 2 * sizeof(assumed_stats)));
     HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_assumed, 2 * sizeof(assumed_stats), hipHostMallocDefault));
-    int rc = reserve_batch(ctx, 64);
-    if (rc) { h2y_ctx_destroy(ctx); return rc; }
+    return reserve_batch(ctx, 64);
+}
+
+int h2y_ctx_create(int device, h2y_ctx **out)
+{
+    if (!out) return fail(nullptr, H2Y_EINVAL, "null out pointer");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev < 1)
+        return fail(nullptr, H2Y_EHIP, "no HIP device (%s): this library has no CPU path", hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(nullptr, H2Y_EINVAL, "device %d out of range (have %d)", device, ndev);
+    h2y_ctx *ctx = new (std::nothrow) h2y_ctx();
+    if (!ctx) return fail(nullptr, H2Y_ENOMEM, "out of host memory");
+    const int rc = ctx_init(ctx, device);
+    if (rc) { /* g_err holds the reason (h2y_last_error(NULL)); nothing of the half-built context survives */
+        h2y_ctx_destroy(ctx);
+        return rc;
+    }
     *out = ctx;
+    return H2Y_OK;
+}
+
+/* Tuning and test knobs, per context.  Nothing in this library reads the environment.
+ *   "t1"      "0" | "1"                 binary32 first tier off / on (default on)
+ *   "groups"  "1" .. "64"               at most this many frame groups (rounded down to a power of two; 1 = off)
+ *   "cols8"   "0" | "1"                 8-column thread tiles for half input (default on)
+ *   "balance" "adaptive" | "off" | "<xcd mask>,<ratio>"   weighted rounds across XCDs (default adaptive)
+ *   "fir"     "auto" | "twopass" | "fused"   how the FIR resampler runs (default auto) */
+int h2y_ctx_set_option(h2y_ctx *ctx, const char *name, const char *value)
+{
+    if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
+    if (!name || !value) return fail(ctx, H2Y_EINVAL, "null option name or value");
+    if (ctx->pending || ctx->streaming) return fail(ctx, H2Y_EINVAL, "a batch is pending or a stream is open");
+    if (!strcmp(name, "t1")) ctx->opt_t1 = value[0] != '0';
+    else if (!strcmp(name, "cols8")) ctx->opt_cols8 = value[0] != '0';
+    else if (!strcmp(name, "groups")) {
+        int v = atoi(value), p = 1;
+        if (v < 1) return fail(ctx, H2Y_EINVAL, "groups must be >= 1");
+        while (2 * p <= v && p < 64) p *= 2;
+        ctx->opt_groups = p;
+    } else if (!strcmp(name, "balance")) {
+        if (!strcmp(value, "adaptive")) ctx->opt_bal_mode = 0;
+        else if (!strcmp(value, "off")) ctx->opt_bal_mode = 1;
+        else {
+            char *end = nullptr;
+            const unsigned long mm = strtoul(value, &end, 0);
+            const double r = (end && *end == ',') ? atof(end + 1) : 0.0;
+            if (!(mm & 0xFFu) || (mm & 0xFFu) == 0xFFu || !(r > 1.0)) return fail(ctx, H2Y_EINVAL, "balance: want adaptive, off or <mask>,<ratio > 1>");
+            ctx->opt_bal_mode = 2;
+            ctx->opt_bal_mask = (uint32_t)(mm & 0xFFu);
+            ctx->opt_bal_rho = r;
+        }
+    } else if (!strcmp(name, "fir")) {
+        if (!strcmp(value, "auto")) ctx->opt_fir = 0;
+        else if (!strcmp(value, "twopass")) ctx->opt_fir = 1;
+        else if (!strcmp(value, "fused")) ctx->opt_fir = 2;
+        else return fail(ctx, H2Y_EINVAL, "fir: want auto, twopass or fused");
+    } else return fail(ctx, H2Y_EINVAL, "unknown option '%s'", name);
     return H2Y_OK;
 }
 
@@ -1088,6 +1099,7 @@ int h2y_matrix_inverse(h2y_ctx *ctx, int width, int height, int in_bit_depth, in
     ctx->last_ms = ms;
     ctx->last_launches = 1;
     ctx->last_name = "k_inverse";
+    ctx->last_variant = "k_inverse";
     return H2Y_OK;
 }
 
@@ -1250,6 +1262,9 @@ int h2y_pic_stats(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3], fl
     const char *why;
     int rc = h2y_desc_check(d, &why);
     if (rc) return fail(ctx, rc, "descriptor: %s", why);
+    if (!d_in || !fminmax || !floor_ceiling) return fail(ctx, H2Y_EINVAL, "null argument");
+    for (int c = 0; c < 3; c++) /* run_stats() takes the scalar-load path for planes that are not 16-byte aligned */
+        if (!d_in[c] || ((uintptr_t)d_in[c] & (sample_bytes(d) - 1))) return fail(ctx, H2Y_EINVAL, "input plane %d is null or not aligned to its sample size", c);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     rc = run_stats(ctx, d, d_in, (int)ctx->frames_cap, nullptr);
     if (rc) return rc;
@@ -1272,6 +1287,11 @@ int h2y_matrix_convert(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3
     const char *why;
     int rc = h2y_desc_check(d, &why);
     if (rc) return fail(ctx, rc, "descriptor: %s", why);
+    if (!d_in || !d_out444) return fail(ctx, H2Y_EINVAL, "null pointer arrays");
+    for (int c = 0; c < 3; c++) { /* the kernels issue 16-byte loads and 8-byte stores */
+        if (!d_in[c] || ((uintptr_t)d_in[c] & 15)) return fail(ctx, H2Y_EINVAL, "input plane %d is null or not 16-byte aligned", c);
+        if (!d_out444[c] || ((uintptr_t)d_out444[c] & 15)) return fail(ctx, H2Y_EINVAL, "output plane %d is null or not 16-byte aligned", c);
+    }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     assumed_stats *as = ctx->h_assumed;
     for (int c = 0; c < 3; c++) {
@@ -1362,6 +1382,7 @@ int h2y_subsample_420(h2y_ctx *ctx, int width, int height, int bit_depth, int ch
 }
 
 const char *h2y_last_kernel_name(const h2y_ctx *ctx) { return ctx ? ctx->last_name : ""; }
+const char *h2y_last_kernel_variant(const h2y_ctx *ctx) { return ctx ? ctx->last_variant.c_str() : ""; }
 
 int h2y_last_kernel_ms(const h2y_ctx *ctx, float *ms, int *launches)
 {

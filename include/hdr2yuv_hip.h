@@ -117,6 +117,13 @@ int h2y_ctx_create(int device, h2y_ctx **out);
 void h2y_ctx_destroy(h2y_ctx *ctx);
 const char *h2y_last_error(const h2y_ctx *ctx); /* ctx may be NULL: global error */
 
+/* Tuning and test knobs of one context, as strings (the library reads nothing from the environment):
+ *   "t1" "0"|"1" (binary32 first tier), "groups" "1".."64" (frame groups), "cols8" "0"|"1" (8-column
+ *   tiles for half input), "balance" "adaptive"|"off"|"<xcd mask>,<ratio>" (weighted rounds across XCDs),
+ *   "fir" "auto"|"twopass"|"fused" (how chroma_resampler_type != 0 runs).  None changes a byte of output.
+ * The reference has no counterpart (its only knobs are the command-line flags in h2y_desc). */
+int h2y_ctx_set_option(h2y_ctx *ctx, const char *name, const char *value);
+
 /* Use the caller's HIP stream (hipStream_t passed as void*) for every launch
  * of this context; NULL restores the context's own stream. */
 int h2y_ctx_set_stream(h2y_ctx *ctx, void *hip_stream);
@@ -214,6 +221,10 @@ int h2y_last_kernel_ms(const h2y_ctx *ctx, float *ms, int *launches);
 /* Name of the kernel those launches ran ("k_fused", "k_fused_t1", "k_fused_lut16",
  * "k_fused_narrow"): the name to look for in a rocprofv3 kernel trace. */
 const char *h2y_last_kernel_name(const h2y_ctx *ctx);
+/* The same with its template arguments and launch shape, e.g. "k_fused_t1<F32,420BOX,YCBCR,PQ_IDENT> groups=8 xcd=1";
+ * "+k_fir420" after the '>' when the chroma went through the two-pass FIR form.  Tests assert on it: which
+ * variant a call took must not depend on what ran before. */
+const char *h2y_last_kernel_variant(const h2y_ctx *ctx);
 
 #ifdef __cplusplus
 }

@@ -207,20 +207,84 @@ def test_batch_device_path_and_stats_redo(ctx, oracle):
         fresh.close()
 
 
-def test_batch_fir(ctx, oracle):
+@pytest.mark.parametrize("mode", ["twopass", "fused", "auto"])
+def test_batch_fir(oracle, mode):
+    """FIR batches through both forms of the FIR path: 11 frames (one fused launch), and 75 frames -- on the
+    two-pass form three sub-batches of 32 frames, so the third reuses the first scratch half behind its event."""
     import torch
 
     rng = np.random.default_rng(22)
     w, hh = 192, 48
     d = h.make_desc(w, hh, dst_depth=10, dst_matrix=h.MATRIX_BT709, resampler=1)
-    host = [_rand_planes(rng, w, hh, h.SAMPLE_F32) for _ in range(11)]  # > FIR sub-batch of 8
-    dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in host]
-    dev_out = [torch.empty(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda") for _ in host]
-    torch.cuda.synchronize()
-    ctx.convert_batch(d, dev_in, dev_out)
     od = _to_oracle_desc(d)
-    for f in range(len(host)):
-        assert np.array_equal(dev_out[f].cpu().numpy().view(np.uint16), oracle.convert_frame(od, host[f])), f
+    fresh = h.Context(0)
+    fresh.set_option("fir", mode)
+    try:
+        for n in (11, 75):
+            host = [_rand_planes(rng, w, hh, h.SAMPLE_F32) for _ in range(n)]
+            host[n // 2][2][5] = np.float32(2.5)  # one frame breaks the statistics hint of the second round
+            dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in host]
+            for rnd in range(2):  # second round: the hint is known (first-tier kernels), one frame redone
+                dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda") for _ in host]
+                torch.cuda.synchronize()
+                fresh.convert_batch(d, dev_in, dev_out)
+                for f in range(n):
+                    got = dev_out[f].cpu().numpy().view(np.uint16)
+                    want = oracle.convert_frame(od, host[f])
+                    assert np.array_equal(got, want), f"{mode} n={n} round {rnd} frame {f}: {np.count_nonzero(got != want)} samples differ"
+    finally:
+        fresh.close()
+
+
+@pytest.mark.parametrize("kind", ["box12", "fir10", "ydzdx16_444", "f16_box10"])
+def test_long_batch_is_split_into_launches(oracle, kind):
+    """BASELINE configs[4]'s single-GPU leg in small: one h2y_convert_batch of 330 frames (> 128 per launch: the
+    host splits it, per-launch statistics offsets, ticket counters per frame of a group), mixed content (black bars
+    on some frames: dense redo lists), one frame in the last launch breaks the statistics hint and is redone."""
+    import torch
+
+    rng = np.random.default_rng(330)
+    n, w, hh = 330, 256, 64
+    if kind == "box12":
+        d = h.make_desc(w, hh, dst_depth=12, dst_matrix=h.MATRIX_BT2020NC, resampler=0)
+    elif kind == "fir10":
+        d = h.make_desc(w, hh, dst_depth=10, dst_matrix=h.MATRIX_BT709, resampler=1)
+    elif kind == "ydzdx16_444":
+        d = h.make_desc(w, hh, dst_depth=16, dst_matrix=h.MATRIX_YDZDX, chroma=h.CHROMA_444)
+    else:
+        d = h.make_desc(w, hh, sample=h.SAMPLE_F16, dst_depth=10, dst_matrix=h.MATRIX_BT2020NC, resampler=0)
+    host = []
+    for k in range(n):
+        planes = [rng.uniform(0.0, 1.0, w * hh).astype(np.float32) for _ in range(3)]
+        for p in planes:
+            p[(13 * k) % 97] = 1.0
+            if k % 41 == 7:
+                p[: 8 * w] = 0.0
+        if k == 300:
+            planes[1][3 * w + 9] = np.float32(2.75)  # ceiling 2 in this frame only
+        if kind == "f16_box10":
+            planes = [p.astype(np.float16).view(np.uint16) for p in planes]
+        host.append(planes)
+    conv = (lambda p: torch.from_numpy(p.view(np.int16)).cuda()) if kind == "f16_box10" else (lambda p: torch.from_numpy(p).cuda())
+    dev_in = [[conv(p) for p in fr] for fr in host]
+    od = _to_oracle_desc(d)
+    want = [oracle.convert_frame(od, fr) for fr in host]
+    fresh = h.Context(0)
+    try:
+        for rnd in range(2):
+            dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda") for _ in host]
+            torch.cuda.synchronize()
+            fresh.convert_batch_enqueue(d, dev_in, dev_out)
+            redone = fresh.batch_finish()
+            assert redone == 1  # frame 300 differs from what was assumed (round 0: frame 0's statistics; round 1: the hint)
+            if rnd == 1:
+                ms, launches = fresh.last_kernel_ms()
+                assert launches >= 3, launches  # 330 frames at no more than 128 per launch
+            for f in range(n):
+                got = dev_out[f].cpu().numpy().view(np.uint16)
+                assert np.array_equal(got, want[f]), f"{kind} round {rnd} frame {f}: {np.count_nonzero(got != want[f])} samples differ"
+    finally:
+        fresh.close()
 
 
 def test_stage_entries(ctx, oracle):
@@ -742,16 +806,15 @@ def test_frame_groups(oracle, kind, n, w, hh):
 def test_weighted_rounds(oracle, balance):
     """The loop-form kernels deal a frame's chunks in two parts -- all blocks, then the blocks on the fast
     XCDs only (frame_walk) -- with weights the host derives from block finish times.  Here the weights are
-    fixed through H2Y_BALANCE, extreme ones included; frames large enough for the full grid (so that the
-    XCD layout applies) and batch lengths with 1, 2 and 8 frame groups; every chunk must be done exactly once."""
-    import os
+    fixed through h2y_ctx_set_option("balance"), extreme ones included; frames large enough for the full grid
+    (so that the XCD layout applies) and batch lengths with 1, 2 and 8 frame groups; every chunk must be done
+    exactly once."""
     import torch
 
     rng = np.random.default_rng(515)
     w, hh = 2048, 1024  # 262 144 tiles: 256 chunks of 1024 (k_fused_t1), 512 of 512 (k_fused2)
-    old = os.environ.get("H2Y_BALANCE")
-    os.environ["H2Y_BALANCE"] = balance
     fresh = h.Context(0)
+    fresh.set_option("balance", balance)
     try:
         for (n, depth, mat, chroma) in ((3, 12, h.MATRIX_BT2020NC, h.CHROMA_420), (8, 12, h.MATRIX_BT2020NC, h.CHROMA_420),
                                         (2, 16, h.MATRIX_YDZDX, h.CHROMA_444)):
@@ -772,12 +835,10 @@ def test_weighted_rounds(oracle, balance):
                 for f in range(n):
                     got = dev_out[f].cpu().numpy().view(np.uint16)
                     assert np.array_equal(got, want[f]), f"{balance} n={n} round {rnd} frame {f}: {np.count_nonzero(got != want[f])} samples differ"
+                if rnd == 1:
+                    assert fresh.last_kernel_name() == ("k_fused_t1" if depth == 12 else "k_fused2")
     finally:
         fresh.close()
-        if old is None:
-            os.environ.pop("H2Y_BALANCE", None)
-        else:
-            os.environ["H2Y_BALANCE"] = old
 
 
 def test_mixed_sequence_on_one_context(oracle):
@@ -831,3 +892,23 @@ def test_mixed_sequence_on_one_context(oracle):
             run(h.make_desc(*big, dst_depth=12, dst_matrix=h.MATRIX_BT2020NC, resampler=1), frames_f32(3, *big), f32)
     finally:
         fresh.close()
+
+
+def test_bench_device_generator_matches_host_generator():
+    """bench.py builds its input on the device (closed form of the SURVEY 8c LCG in 64-bit integers): same bits as
+    hdr2yuv_amd/synth.py, which tests/test_host_logic.py pins to the oracle's generator."""
+    import importlib.util
+    import torch
+
+    from hdr2yuv_amd.synth import synth_frame
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(GOLD), "..", "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    for (w, hh, f16) in ((256, 64, False), (1920, 1080, False), (512, 128, True)):
+        gen = bench.DeviceSynth(3 * w * hh, torch.device("cuda", 0))
+        for k in (0, 1, 63, 511):
+            got = [p.cpu().numpy() for p in gen.frame(w, hh, k, f16)]
+            want = synth_frame(w, hh, k, f16)
+            for c in range(3):
+                assert np.array_equal(got[c].view(np.uint16) if f16 else got[c].view(np.uint32), want[c].view(np.uint16) if f16 else want[c].view(np.uint32)), (w, hh, f16, k, c)

@@ -88,3 +88,40 @@ def test_two_rank_frame_shard_gloo(tmp_path, oracle):
     want = np.concatenate([oracle.convert_frame(d, oracle.synth_frame(w, h, k)) for k in range(n_frames)])
     got = np.fromfile(os.path.join(str(tmp_path), "out.yuv"), dtype=np.uint16)
     assert np.array_equal(got, want)  # same bytes as one process appending frame after frame
+
+
+def _run_bench(args, env_extra=None):
+    import json
+    import subprocess
+
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=300)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_launches_n_ranks_by_itself():
+    """`python bench.py --gpus 2` with no torchrun around it starts two ranks (rehearsal form: gloo, no device,
+    nothing measured): rank r owns frames [r*F, (r+1)*F), the job's time is the slowest rank's, ONE JSON line."""
+    r, out = _run_bench(["--gpus", "2", "--rehearse", "--frames", "5", "--steps", "3"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert out["rehearsal"] is True and out["n_gpus"] == 2 and out["value"] is None
+    assert [p["frames"] for p in out["per_rank"]] == [[0, 5], [5, 10]]
+    assert out["seconds_max"] == 1.25 and out["pixels_total"] == 2 * 5 * 3840 * 2160 * 3
+    assert len([ln for ln in r.stdout.splitlines() if ln.startswith("{")]) == 1
+
+
+def test_bench_refuses_fewer_gpus_than_asked():
+    """No silent fall-back to one GPU: without N visible devices `--gpus N` exits non-zero and prints no JSON line;
+    neither does a WORLD_SIZE that differs from --gpus."""
+    import torch
+
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs are visible here")
+    r, out = _run_bench(["--gpus", "2", "--steps", "1", "--warmup", "0"])
+    assert r.returncode != 0 and out is None and "refusing" in r.stderr
+    r, out = _run_bench(["--gpus", "1", "--rehearse"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and out is None and "refusing" in r.stderr

@@ -28,7 +28,7 @@ EXPORTS = [
     "h2y_abi_version", "h2y_frame_bytes", "h2y_plane_bytes", "h2y_desc_check", "h2y_ctx_create", "h2y_ctx_destroy",
     "h2y_last_error", "h2y_ctx_set_stream", "h2y_convert_frame", "h2y_convert_batch", "h2y_convert_batch_enqueue",
     "h2y_batch_finish", "h2y_pic_stats", "h2y_matrix_convert", "h2y_subsample_420", "h2y_last_kernel_ms", "h2y_last_kernel_name", "h2y_last_kernel_variant",
-    "h2y_matrix_inverse", "h2y_ctx_set_option", "h2y_stream_open", "h2y_stream_input", "h2y_stream_submit", "h2y_stream_output", "h2y_stream_close",
+    "h2y_matrix_inverse", "h2y_upsample_444", "h2y_inverse_420", "h2y_ctx_set_option", "h2y_stream_open", "h2y_stream_input", "h2y_stream_submit", "h2y_stream_output", "h2y_stream_close",
 ]
 
 
@@ -91,7 +91,7 @@ def set_library_path(path: str) -> None:
 
 def build_library(force: bool = False) -> str:
     """hipcc --offload-arch=gfx950 build of the kernels + shim, in-tree."""
-    args = ["make", "-C", os.path.join(_HERE, "csrc"), "--no-print-directory"]
+    args = ["make", "-j4", "-C", os.path.join(_HERE, "csrc"), "--no-print-directory"]
     if force:
         args.append("-B")
     subprocess.run(args, check=True)
@@ -150,6 +150,10 @@ def load_library():
     L.h2y_subsample_420.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     L.h2y_matrix_inverse.restype = C.c_int
     L.h2y_matrix_inverse.argtypes = [C.c_void_p] + [C.c_int] * 6 + [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    L.h2y_upsample_444.restype = C.c_int
+    L.h2y_upsample_444.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p]
+    L.h2y_inverse_420.restype = C.c_int
+    L.h2y_inverse_420.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.h2y_stream_open.restype = C.c_int
     L.h2y_stream_open.argtypes = [C.c_void_p, C.POINTER(H2YDesc), C.c_int]
     L.h2y_stream_input.restype = C.c_int
@@ -291,6 +295,16 @@ class Context:
         ip = (C.c_void_p * 3)(*[self._ptr(p) for p in in_planes])
         op = (C.c_void_p * 3)(*[self._ptr(p) for p in out_planes])
         self._check(self.lib.h2y_matrix_inverse(self.h, width, height, in_depth, in_full_range, in_matrix, out_depth, ip, op))
+
+    def upsample_444(self, width, height, algorithm, min_cv, max_cv, src, dst) -> None:
+        """Subsample420to444: device U16 (height/2 x width/2) plane -> device U16 (height x width) plane."""
+        self._check(self.lib.h2y_upsample_444(self.h, width, height, algorithm, min_cv, max_cv, self._ptr(src), self._ptr(dst)))
+
+    def inverse_420(self, width, height, in_depth, in_full_range, in_matrix, out_depth, algorithm, in_planes, out_planes) -> None:
+        """Device U16 4:2:0 planes (Y, Cb/Dz, Cr/Dx) -> device U16 planes (G, B, R): upsample, then matrix_inverse."""
+        ip = (C.c_void_p * 3)(*[self._ptr(p) for p in in_planes])
+        op = (C.c_void_p * 3)(*[self._ptr(p) for p in out_planes])
+        self._check(self.lib.h2y_inverse_420(self.h, width, height, in_depth, in_full_range, in_matrix, out_depth, algorithm, ip, op))
 
     # ---- host <-> device pipeline -----------------------------------------------------------
     def stream_open(self, d, depth=3) -> None:

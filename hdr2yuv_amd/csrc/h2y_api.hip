@@ -113,6 +113,8 @@ struct h2y_ctx {
     assumed_stats *d_assumed = nullptr, *h_assumed = nullptr; /* [2]: [0] batch, [1] redo */
     uint16_t *d_tmp = nullptr;
     size_t tmp_cap = 0;
+    uint16_t *d_up = nullptr; /* h2y_inverse_420(): the two upsampled chroma planes */
+    size_t up_cap = 0;
 
     /* staging for the host-buffer entry */
     void *d_in = nullptr;
@@ -846,6 +848,7 @@ void h2y_ctx_destroy(h2y_ctx *ctx)
     (void)hipFree(ctx->d_assumed);
     (void)hipHostFree(ctx->h_assumed);
     (void)hipFree(ctx->d_tmp);
+    (void)hipFree(ctx->d_up);
     (void)hipFree(ctx->d_in);
     (void)hipFree(ctx->d_out);
     if (ctx->fir_stream) {
@@ -1101,6 +1104,58 @@ int h2y_matrix_inverse(h2y_ctx *ctx, int width, int height, int in_bit_depth, in
     ctx->last_name = "k_inverse";
     ctx->last_variant = "k_inverse";
     return H2Y_OK;
+}
+
+/* Subsample420to444(), convert.cpp:1869-1986 */
+static int upsample_launch(h2y_ctx *ctx, int width, int height, int algorithm, unsigned min_cv, unsigned max_cv, const uint16_t *s0,
+                           const uint16_t *s1, uint16_t *d0, uint16_t *d1)
+{
+    up_args a;
+    a.src0 = s0; a.src1 = s1; a.dst0 = d0; a.dst1 = d1;
+    a.width = width; a.height = height;
+    a.algorithm = algorithm;
+    a.fmin = (float)min_cv; a.fmax = (float)max_cv;
+    HIP_TRY(ctx, h2y_launch_up444(ctx->stream, a));
+    return H2Y_OK;
+}
+
+int h2y_upsample_444(h2y_ctx *ctx, int width, int height, int algorithm, unsigned min_cv, unsigned max_cv, const uint16_t *d_src,
+                     uint16_t *d_dst)
+{
+    if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
+    if (ctx->pending || ctx->streaming) return fail(ctx, H2Y_EINVAL, "a batch is pending or a stream is open");
+    /* odd sizes: the reference's FIR branch reads rows of its intermediate it never wrote (convert.cpp:1949 walks
+     * j < height over 2 * (height / 2) written rows): no defined bytes */
+    if (width < 2 || height < 2 || (width & 1) || (height & 1) || width > 32766 || height > 32766)
+        return fail(ctx, H2Y_EINVAL, "upsample: width and height must be even, 2..32766 (the reference takes them as short)");
+    if (min_cv > max_cv || max_cv > 65535u) return fail(ctx, H2Y_EINVAL, "upsample: need minCV <= maxCV <= 65535");
+    if (!d_src || !d_dst || ((uintptr_t)d_src & 1) || ((uintptr_t)d_dst & 3)) return fail(ctx, H2Y_EINVAL, "upsample: null pointer, or the result plane is not 4-byte aligned");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int rc = upsample_launch(ctx, width, height, algorithm, min_cv, max_cv, d_src, nullptr, d_dst, nullptr);
+    if (rc) return rc;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return H2Y_OK;
+}
+
+int h2y_inverse_420(h2y_ctx *ctx, int width, int height, int in_bit_depth, int in_full_range, int in_matrix_coeffs, int out_bit_depth,
+                    int algorithm, const uint16_t *const d_in[3], uint16_t *const d_out[3])
+{
+    if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
+    if (ctx->pending || ctx->streaming) return fail(ctx, H2Y_EINVAL, "a batch is pending or a stream is open");
+    if (width < 2 || height < 2 || (width & 3) || (height & 1) || width > 32766 || height > 32766)
+        return fail(ctx, H2Y_EINVAL, "4:2:0 inverse: width a multiple of 4 and height even, up to 32766"); /* the upsampled planes feed 8-byte loads */
+    if (in_bit_depth < 8 || in_bit_depth > 16) return fail(ctx, H2Y_EINVAL, "bit depths must be 8..16");
+    if (!d_in || !d_in[0] || !d_in[1] || !d_in[2]) return fail(ctx, H2Y_EINVAL, "null pointer arrays");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t npix = (size_t)width * height, plane_al = (npix * sizeof(uint16_t) + 255) & ~(size_t)255;
+    int rc = ensure(ctx, ctx->d_up, ctx->up_cap, 2 * plane_al);
+    if (rc) return rc;
+    uint16_t *cb = ctx->d_up, *cr = reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(ctx->d_up) + plane_al);
+    /* yuv2tiff.cpp:92-93,142-154: minCV 0, maxCV 2^depth - 1 */
+    rc = upsample_launch(ctx, width, height, algorithm, 0u, (1u << in_bit_depth) - 1u, d_in[1], d_in[2], cb, cr);
+    if (rc) return rc;
+    const uint16_t *full[3] = {d_in[0], cb, cr};
+    return h2y_matrix_inverse(ctx, width, height, in_bit_depth, in_full_range, in_matrix_coeffs, out_bit_depth, full, d_out);
 }
 
 /* ---- streaming pipeline ------------------------------------------------------

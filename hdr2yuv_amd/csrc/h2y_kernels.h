@@ -131,6 +131,14 @@ struct inverse_args {
     int shift, shift_right;
 };
 
+struct up_args { /* k_up444: one or two chroma planes, (width/2 x height/2) -> (width x height) */
+    const uint16_t *src0, *src1; /* src1 may be NULL (one plane) */
+    uint16_t *dst0, *dst1;
+    int width, height;           /* of the 4:4:4 result; both even */
+    int algorithm;               /* 0 replication, else the FIR pair */
+    float fmin, fmax;            /* (float) of minCV / maxCV, convert.cpp:1932-1934 */
+};
+
 #ifdef H2Y_BLOCK_TIMES
 void h2y_dump_block_times(const char *path); /* timing experiments only */
 #endif
@@ -144,6 +152,7 @@ hipError_t h2y_launch_stats(int in_kind, int grid, hipStream_t st, const stats_a
 hipError_t h2y_launch_stats_final(int n_frames, hipStream_t st, const final_args &a);
 hipError_t h2y_launch_fir420(hipStream_t st, const fir_args &a);
 hipError_t h2y_launch_inverse(int grid, hipStream_t st, const inverse_args &a);
+hipError_t h2y_launch_up444(hipStream_t st, const up_args &a);
 hipError_t h2y_launch_box420(hipStream_t st, const uint16_t *src, uint16_t *dst, int W, int H);
 
 #endif

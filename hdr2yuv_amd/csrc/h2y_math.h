@@ -1028,5 +1028,40 @@ H2Y_FN uint32_t fir_v(float m5, float m4, float m3, float m2, float m1, float m0
     return fir_clamp_trunc(acc + 0.5f, fmaxcv);
 }
 
+/* ---- Subsample420to444, convert.cpp:1869-1986 -----------------------------------------------
+ * clamp to [lo, hi] and truncate (:1932-1934 and alike); t is never NaN (sums of finite samples) */
+H2Y_FN uint32_t up_clamp_trunc(float t, float lo, float hi)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_fmed3f(t, lo, hi);
+#else
+    if (t > hi) t = hi;
+    if (t < lo) t = lo;
+    return (uint32_t)t;
+#endif
+}
+/* vertical stage, :1925-1931 (even output rows: a..f = rows j-3..j+2) and :1936-1942 (odd rows: the same taps
+ * mirrored, a..f = rows j+3..j-2).  Products and sums left to right in float; the reference's trailing double
+ * "+0.5" rounded back to float is the float addition (one rounding of the exact sum either way). */
+H2Y_FN uint32_t up_fir6(float a, float b, float c, float d, float e, float f, float lo, float hi)
+{
+    const float c3 = 3.0f / 256.0f, c16 = 16.0f / 256.0f, c67 = 67.0f / 256.0f, c227 = 227.0f / 256.0f, c32 = 32.0f / 256.0f,
+                c7 = 7.0f / 256.0f;
+    float acc = c3 * a - c16 * b;
+    acc = acc + c67 * c;
+    acc = acc + c227 * d;
+    acc = acc - c32 * e;
+    acc = acc + c7 * f;
+    return up_clamp_trunc(acc + 0.5f, lo, hi);
+}
+/* horizontal stage, odd samples, :1972-1977: m0..m5 = intermediate columns i-2 .. i+3 */
+H2Y_FN uint32_t up_fir_odd(float m0, float m1, float m2, float m3, float m4, float m5, float lo, float hi)
+{
+    const float c21 = 21.0f / 256.0f, c52 = 52.0f / 256.0f, c159 = 159.0f / 256.0f;
+    float acc = c21 * (m0 + m5) - c52 * (m1 + m4);
+    acc = acc + c159 * (m2 + m3);
+    return up_clamp_trunc(acc + 0.5f, lo, hi);
+}
+
 } // namespace h2y
 #endif /* H2Y_MATH_H */

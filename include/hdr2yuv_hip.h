@@ -185,11 +185,28 @@ int h2y_subsample_420(h2y_ctx *ctx, int width, int height, int bit_depth,
  * of 12 bits at any bit depth, only matrix_coeffs 1 (BT.709) takes the Y'CbCr equations -- every other
  * value, BT.2020 included, the Y'DzDx ones --, matrix_coeffs 0 is refused (the reference exits), the
  * result is clamped to the INPUT picture's video (or full) range and shifted to out_bit_depth.
- * 4:2:0 input has no defined result in the reference (it indexes all planes at full resolution;
- * Subsample420to444 is compiled out): upsample first. */
+ * The function indexes all three planes at full resolution: 4:2:0 input goes through h2y_upsample_444 first
+ * (h2y_inverse_420 does both). */
 int h2y_matrix_inverse(h2y_ctx *ctx, int width, int height, int in_bit_depth, int in_full_range,
                        int in_matrix_coeffs, int out_bit_depth, const uint16_t *const d_in[3],
                        uint16_t *const d_out[3]);
+
+/* Subsample420to444() (convert.cpp:1869-1986; the same function is yuv2tiff.cpp:575-692, called at :341-342;
+ * in convert.cpp only its call site :1576-1577 is under #if 0): one U16 chroma plane of (width/2) x (height/2)
+ * samples -> width x height, on the device.  algorithm 0 replicates samples (:1871-1881); any other value runs
+ * the FIR pair (:1882-1983): vertical (3 -16 67 227 -32 7)/256 per row parity into a U16 intermediate, then
+ * even samples copied and odd samples (21 -52 159 159 -52 21)/256; edges replicate; every stage clamps to
+ * [min_cv, max_cv] and truncates.  width and height even (for odd sizes the reference reads rows of its
+ * intermediate that it never wrote); d_dst 4-byte aligned. */
+int h2y_upsample_444(h2y_ctx *ctx, int width, int height, int algorithm, unsigned min_cv, unsigned max_cv,
+                     const uint16_t *d_src, uint16_t *d_dst);
+
+/* The .yuv 4:2:0 -> RGB flow (yuv2tiff.cpp:341-342 followed by its pixel loop = matrix_inverse()):
+ * d_in = Y (width x height), Cb/Dz and Cr/Dx (width/2 x height/2); both chroma planes are upsampled with
+ * minCV 0 / maxCV 2^in_bit_depth - 1 (yuv2tiff.cpp:92-93,142-154) into scratch the context owns, then
+ * h2y_matrix_inverse() runs on the three full planes.  width a multiple of 4, height even. */
+int h2y_inverse_420(h2y_ctx *ctx, int width, int height, int in_bit_depth, int in_full_range, int in_matrix_coeffs,
+                    int out_bit_depth, int algorithm, const uint16_t *const d_in[3], uint16_t *const d_out[3]);
 
 /* ---- host <-> device pipeline --------------------------------------------
  * The reference reads a frame, converts it and appends it to the .yuv, one after the other

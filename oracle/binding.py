@@ -121,9 +121,19 @@ class Oracle:
         L.h2y_oracle_matrix_inverse.restype = C.c_int
         L.h2y_oracle_matrix_inverse.argtypes = [C.c_int] * 6 + [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
         self._inverse_fn = L.h2y_oracle_matrix_inverse
+        L.h2y_oracle_up444.restype = None
+        L.h2y_oracle_up444.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_uint]
 
     def pq(self, x: float) -> float:
         return float(self.lib.h2y_oracle_pq10000_r(float(x)))
+
+    def up444(self, src: np.ndarray, width: int, height: int, algorithm: int, min_cv: int, max_cv: int, fill: int = 0) -> np.ndarray:
+        """Subsample420to444 on a (height//2, width//2) plane -> (height, width); samples the function never writes
+        (odd sizes) keep `fill`."""
+        src = np.ascontiguousarray(src, dtype=np.uint16).reshape(height >> 1, width >> 1)
+        dst = np.full((height, width), fill, dtype=np.uint16)
+        self.lib.h2y_oracle_up444(dst.ctypes.data, src.ctypes.data, width, height, algorithm, min_cv, max_cv)
+        return dst
 
     def matrix_inverse(self, width, height, in_depth, in_full_range, in_matrix, out_depth, planes):
         """matrix_inverse() on three U16 4:4:4 planes (Y, Cb/Dz, Cr/Dx) -> (G, B, R) planes."""
@@ -212,9 +222,17 @@ class Ref:
         L.h2y_ref_matrix_inverse.restype = C.c_int
         L.h2y_ref_matrix_inverse.argtypes = [C.c_int] * 6 + [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
         self._inverse_fn = L.h2y_ref_matrix_inverse
+        L.h2y_ref_up444.restype = C.c_int
+        L.h2y_ref_up444.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_uint]
 
     def pq(self, x: float) -> float:
         return float(self.lib.h2y_ref_pq10000_r(float(x)))
+
+    def up444(self, src: np.ndarray, width: int, height: int, algorithm: int, min_cv: int, max_cv: int, fill: int = 0) -> np.ndarray:
+        src = np.ascontiguousarray(src, dtype=np.uint16).reshape(height >> 1, width >> 1)
+        dst = np.full((height, width), fill, dtype=np.uint16)
+        self.lib.h2y_ref_up444(src.ctypes.data, dst.ctypes.data, width, height, algorithm, min_cv, max_cv)
+        return dst
 
     def convert_frame(self, d: H2YDesc, planes, want_444: bool = False):
         out = np.empty(frame_samples(d), dtype=np.uint16)

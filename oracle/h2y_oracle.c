@@ -354,6 +354,67 @@ void h2y_oracle_sub420_fir(uint16_t *dst, const uint16_t *src, int width, int he
     free(mid);
 }
 
+/* ---- Subsample420to444(), convert.cpp:1869-1986 (also yuv2tiff.cpp:575-692) ----
+ * src: (width/2) x (height/2) plane, dst: width x height plane, both row-major here (the reference
+ * indexes arrays of column pointers [col][row]; the arithmetic does not depend on that).
+ * algorithm 0: sample replication (:1871-1881).  Otherwise (:1882-1983): vertical 6-tap pair
+ * (3 -16 67 227 -32 7)/256 per output-row parity into a (width/2) x height intermediate that is
+ * clamped and truncated to unsigned short, then horizontally even samples copied and odd samples
+ * from (21 -52 159 159 -52 21)/256, edges replicated by index clamping. */
+void h2y_oracle_up444(uint16_t *dst, const uint16_t *src, int width, int height, int algorithm,
+                      unsigned minCV, unsigned maxCV)
+{
+    const int w2 = width >> 1, h2 = height >> 1; /* short w422 = width>>1, h420 = height>>1, :1892-1893 */
+    if (algorithm == 0) {
+        for (int l = 0; l < height / 2; l++)
+            for (int p = 0; p < width / 2; p++) {
+                const uint16_t v = src[(size_t)l * w2 + p];
+                dst[(size_t)(2 * l) * width + 2 * p] = v;
+                dst[(size_t)(2 * l) * width + 2 * p + 1] = v;
+                dst[(size_t)(2 * l + 1) * width + 2 * p] = v;
+                dst[(size_t)(2 * l + 1) * width + 2 * p + 1] = v;
+            }
+        return;
+    }
+    /* rows 2*h2 .. height-1 and columns 2*w2 .. width-1 (odd sizes) are never written by the reference */
+    uint16_t *mid = (uint16_t *)malloc((size_t)(height > 0 ? height : 1) * (w2 > 0 ? w2 : 1) * sizeof(uint16_t));
+    const float scale = 256.0f;
+    const float c3 = 3.0f / scale, c16 = 16.0f / scale, c67 = 67.0f / scale, c227 = 227.0f / scale, c32 = 32.0f / scale, c7 = 7.0f / scale;
+    const float fmaxCV = (float)maxCV, fminCV = (float)minCV;
+    for (int i = 0; i < w2; i++)
+        for (int j = 0; j < h2; j++) {
+#define S(r) ((float)src[(size_t)clampi((r), 0, h2 - 1) * w2 + i])
+            /* :1925-1931: products and sums left to right in float, the trailing +0.5 a double add rounded back */
+            float acc = c3 * S(j - 3) - c16 * S(j - 2) + c67 * S(j - 1) + c227 * S(j) - c32 * S(j + 1) + c7 * S(j + 2);
+            float t = (float)((double)acc + 0.5);
+            if (t > fmaxCV) t = fmaxCV;
+            if (t < fminCV) t = fminCV;
+            mid[(size_t)(2 * j) * w2 + i] = (uint16_t)t;
+            /* :1936-1944 */
+            acc = c3 * S(j + 3) - c16 * S(j + 2) + c67 * S(j + 1) + c227 * S(j) - c32 * S(j - 1) + c7 * S(j - 2);
+            t = (float)((double)acc + 0.5);
+            if (t > fmaxCV) t = fmaxCV;
+            if (t < fminCV) t = fminCV;
+            mid[(size_t)(2 * j + 1) * w2 + i] = (uint16_t)t;
+#undef S
+        }
+    /* :1949-1979; the reference walks j < height over the intermediate, whose rows >= 2*h2 (odd height) it never
+     * wrote (malloc'ed garbage): here they are not produced at all */
+    const float d21 = 21.0f / scale, d52 = 52.0f / scale, d159 = 159.0f / scale;
+    for (int j = 0; j < 2 * h2; j++)
+        for (int i = 0; i < w2; i++) {
+#define D(c) ((float)mid[(size_t)j * w2 + clampi((c), 0, w2 - 1)])
+            dst[(size_t)j * width + 2 * i] = mid[(size_t)j * w2 + i];
+            float acc = d21 * (D(i - 2) + D(i + 3)) - d52 * (D(i - 1) + D(i + 2)) + d159 * (D(i) + D(i + 1));
+            float t = (float)((double)acc + 0.5);
+            if (t > fmaxCV) t = fmaxCV;
+            if (t < fminCV) t = fminCV;
+            dst[(size_t)j * width + 2 * i + 1] = (uint16_t)t;
+#undef D
+        }
+    free(mid);
+}
+
 /* ---- write_yuv() per-sample arithmetic, tiff.cpp:457-550 --------------- */
 void h2y_oracle_yuv_clamp(uint16_t *plane, size_t n, int down_shift, int full_range,
                           unsigned lo, unsigned hi, uint64_t maxCV)

@@ -63,6 +63,11 @@ void h2y_oracle_sub420_box(uint16_t *dst, const uint16_t *src, int width, int he
 void h2y_oracle_sub420_fir(uint16_t *dst, const uint16_t *src, int width, int height,
                            uint64_t minCV, uint64_t maxCV);
 
+/* Subsample420to444, convert.cpp:1869-1986: (width/2 x height/2) -> (width x height), row-major planes;
+ * algorithm 0 = replication, else the 6-tap / 6-tap FIR pair */
+void h2y_oracle_up444(uint16_t *dst, const uint16_t *src, int width, int height, int algorithm,
+                      unsigned minCV, unsigned maxCV);
+
 /* write_yuv per-sample arithmetic, tiff.cpp:394,457-550, in place on a plane */
 void h2y_oracle_yuv_clamp(uint16_t *plane, size_t n, int down_shift, int full_range,
                           unsigned lo, unsigned hi, uint64_t maxCV);

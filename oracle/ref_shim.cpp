@@ -53,6 +53,7 @@ int h2y_ref_convert_frame(const h2y_desc *d, const void *const in_planes[3], uin
 int h2y_ref_sub420(const uint16_t *src, uint16_t *dst, int width, int height, int bit_depth, int fir);
 int h2y_ref_matrix_inverse(int width, int height, int in_bit_depth, int in_full_range, int in_matrix, int out_bit_depth,
                            const uint16_t *const in_planes[3], uint16_t *const out_planes[3]);
+int h2y_ref_up444(const uint16_t *src, uint16_t *dst, int width, int height, int algorithm, unsigned minCV, unsigned maxCV);
 
 } // extern "C"
 
@@ -60,7 +61,37 @@ float PQ10000_r(float L); /* convert.cpp:56 (not declared in hdr.h) */
 void Subsample444to420_FIR(unsigned short *, unsigned short *, short, short, unsigned long, unsigned long);
 void Subsample444to420_box(unsigned short *, unsigned short *, short, short, unsigned long, unsigned long);
 
+void Subsample420to444(unsigned short **src, unsigned short **dst, short width, short height, short algorithmn, unsigned short minCV,
+                       unsigned short maxCV); /* convert.cpp:1869: defined and compiled, only its call site (:1576) is under #if 0 */
+
 float h2y_ref_pq10000_r(float L) { return PQ10000_r(L); }
+
+/* The reference's Subsample420to444() on row-major planes: it takes arrays of COLUMN pointers
+ * (src[col][row], dst[col][row]), which are built here and copied back. */
+int h2y_ref_up444(const uint16_t *src, uint16_t *dst, int width, int height, int algorithm, unsigned minCV, unsigned maxCV)
+{
+    MuteStdout mute;
+    const int w2 = width >> 1, h2 = height >> 1;
+    unsigned short **scol = (unsigned short **)malloc(sizeof(unsigned short *) * (w2 > 0 ? w2 : 1));
+    unsigned short **dcol = (unsigned short **)malloc(sizeof(unsigned short *) * (width > 0 ? width : 1));
+    for (int i = 0; i < w2; i++) {
+        scol[i] = (unsigned short *)malloc(sizeof(unsigned short) * (h2 > 0 ? h2 : 1));
+        for (int j = 0; j < h2; j++) scol[i][j] = src[(size_t)j * w2 + i];
+    }
+    for (int i = 0; i < width; i++) {
+        dcol[i] = (unsigned short *)malloc(sizeof(unsigned short) * height);
+        for (int j = 0; j < height; j++) dcol[i][j] = dst[(size_t)j * width + i]; /* what the function leaves untouched stays the caller's */
+    }
+    Subsample420to444(scol, dcol, (short)width, (short)height, (short)algorithm, (unsigned short)minCV, (unsigned short)maxCV);
+    for (int i = 0; i < width; i++) {
+        for (int j = 0; j < height; j++) dst[(size_t)j * width + i] = dcol[i][j];
+        free(dcol[i]);
+    }
+    for (int i = 0; i < w2; i++) free(scol[i]);
+    free(scol);
+    free(dcol);
+    return 0;
+}
 
 int h2y_ref_sub420(const uint16_t *src, uint16_t *dst, int width, int height, int bit_depth, int fir)
 {

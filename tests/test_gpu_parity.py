@@ -257,9 +257,9 @@ def test_long_batch_is_split_into_launches(oracle, kind):
     for k in range(n):
         planes = [rng.uniform(0.0, 1.0, w * hh).astype(np.float32) for _ in range(3)]
         for p in planes:
-            p[(13 * k) % 97] = 1.0
             if k % 41 == 7:
                 p[: 8 * w] = 0.0
+            p[8 * w + (13 * k) % 97] = 1.0  # pic_stats ceiling 1 for every frame
         if k == 300:
             planes[1][3 * w + 9] = np.float32(2.75)  # ceiling 2 in this frame only
         if kind == "f16_box10":
@@ -912,3 +912,49 @@ def test_bench_device_generator_matches_host_generator():
             want = synth_frame(w, hh, k, f16)
             for c in range(3):
                 assert np.array_equal(got[c].view(np.uint16) if f16 else got[c].view(np.uint32), want[c].view(np.uint16) if f16 else want[c].view(np.uint32)), (w, hh, f16, k, c)
+
+
+@pytest.mark.parametrize("w,hh", [(2, 2), (4, 2), (6, 10), (64, 32), (130, 18), (258, 70), (1920, 1080)])
+def test_upsample_444(ctx, oracle, w, hh):
+    """h2y_upsample_444 (Subsample420to444, convert.cpp:1869-1986) vs the oracle, itself pinned to the
+    compiled reference function: replication and the FIR pair, tile edges and picture edges (sizes below one
+    tile, one sample past a tile), full and video-range clamps, extreme code values."""
+    import torch
+
+    rng = np.random.default_rng(w * 7 + hh)
+    for depth in (10, 16):
+        maxcv = (1 << depth) - 1
+        src = rng.integers(0, 1 << depth, (hh // 2, w // 2)).astype(np.uint16)
+        src.flat[: min(4, src.size)] = [0, maxcv, maxcv, 0][: min(4, src.size)]
+        dsrc = torch.from_numpy(src.view(np.int16)).cuda()
+        for alg in (0, 1, 7):
+            for (lo, hi) in ((0, maxcv), (16 << (depth - 8), 240 << (depth - 8))):
+                ddst = torch.zeros(hh * w, dtype=torch.int16, device="cuda")
+                ctx.upsample_444(w, hh, alg, lo, hi, dsrc, ddst)
+                got = ddst.cpu().numpy().view(np.uint16).reshape(hh, w)
+                want = oracle.up444(src, w, hh, alg, lo, hi)
+                assert np.array_equal(got, want), (w, hh, depth, alg, lo, hi, int(np.count_nonzero(got != want)))
+    with pytest.raises(h.H2YError):
+        ctx.upsample_444(w + 1, hh, 1, 0, 1023, dsrc, ddst)  # odd width: no defined bytes in the reference
+
+
+def test_inverse_420_flow(ctx, oracle):
+    """.yuv 4:2:0 -> G,B,R: both chroma planes upsampled (yuv2tiff.cpp:341-342), then matrix_inverse."""
+    import torch
+
+    rng = np.random.default_rng(420)
+    for (w, hh) in ((256, 64), (68, 10)):
+        n = w * hh
+        for (mat, ind, outd, full, alg) in ((9, 12, 16, 0, 1), (1, 10, 10, 0, 1), (11, 12, 16, 0, 0), (1, 12, 12, 1, 1)):
+            y = rng.integers(0, 1 << ind, n).astype(np.uint16)
+            cb = rng.integers(0, 1 << ind, n // 4).astype(np.uint16)
+            cr = rng.integers(0, 1 << ind, n // 4).astype(np.uint16)
+            din = [torch.from_numpy(p.view(np.int16)).cuda() for p in (y, cb, cr)]
+            dout = [torch.zeros(n, dtype=torch.int16, device="cuda") for _ in range(3)]
+            ctx.inverse_420(w, hh, ind, full, mat, outd, alg, din, dout)
+            maxcv = (1 << ind) - 1
+            full_planes = [y, oracle.up444(cb, w, hh, alg, 0, maxcv).reshape(-1), oracle.up444(cr, w, hh, alg, 0, maxcv).reshape(-1)]
+            want = oracle.matrix_inverse(w, hh, ind, full, mat, outd, full_planes)
+            for c in range(3):
+                got = dout[c].cpu().numpy().view(np.uint16)
+                assert np.array_equal(got, want[c]), (w, hh, mat, ind, outd, full, alg, c, int(np.count_nonzero(got != want[c])))

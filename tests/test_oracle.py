@@ -148,3 +148,20 @@ def test_matrix_inverse_restatement_equals_reference(oracle, ref):
             b = ref.matrix_inverse(w, hh, ind, full, mat, outd, planes)
             for c in range(3):
                 assert np.array_equal(a[c], b[c]), (mat, ind, outd, full, c)
+
+
+def test_upsampler_restatement_equals_reference(oracle, ref):
+    """Subsample420to444 (convert.cpp:1869-1986) restated vs the compiled function in oracle/_ref
+    (only its call site is under #if 0): replication and the FIR pair, every bit depth's clamp, sizes down to the
+    smallest where every edge ternary fires, extreme code values."""
+    rng = np.random.default_rng(44)
+    for (w, h) in ((2, 2), (4, 2), (2, 6), (8, 8), (12, 4), (64, 32), (130, 18), (256, 66)):
+        for depth in (8, 10, 12, 16):
+            maxcv = (1 << depth) - 1
+            src = rng.integers(0, 1 << depth, (h // 2, w // 2)).astype(np.uint16)
+            src.flat[: min(4, src.size)] = [0, maxcv, maxcv, 0][: min(4, src.size)]
+            for alg in (0, 1):
+                for (lo, hi) in ((0, maxcv), (16 << (depth - 8), 240 << (depth - 8))):
+                    a = oracle.up444(src, w, h, alg, lo, hi)
+                    b = ref.up444(src, w, h, alg, lo, hi)
+                    assert np.array_equal(a, b), (w, h, depth, alg, lo, hi, int(np.count_nonzero(a != b)))

@@ -340,7 +340,10 @@ fused_variant pick_variant(const h2y_ctx *ctx, const h2y_desc *d, const pix_para
         v.pipe = ident ? 1 : 2; /* 2 is always valid: (x - 0) / 1 == x exactly */
         if (pp.convert_transfer == 2) v.pipe = 0; /* generic transfer pair: runtime kernel, careful tier */
         /* binary32 first tier where few pixels would fall through it (moderate bit depths) */
-        if ((v.pipe == 1 || v.pipe == 2) && v.in_kind != H2Y_IN_U16 && (d->height & 1) == 0 && ctx->opt_t1 && t1_bounds(pp, sn)) v.pipe += 3;
+        if ((v.pipe == 1 || v.pipe == 2) && v.in_kind != H2Y_IN_U16 && (d->height & 1) == 0 && ctx->opt_t1 && t1_bounds(pp, sn)) {
+            v.pipe += 3;
+            v.t1_ok = true;
+        }
         /* half input with the identity normalisation: the whole transfer is a 64 KB table */
         if (ident && v.in_kind == H2Y_IN_F16 && v.even_h && (pp.mode == H2Y_MODE_YCBCR || pp.mode == H2Y_MODE_YDZDX)) v.pipe = 3;
     }
@@ -434,6 +437,100 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
             ok = ok && (reinterpret_cast<uintptr_t>(frames[i].out) & 15u) == 0;
         }
         var.cols8 = ok;
+    }
+    if (out_kind == H2Y_OUT_444TMP && ctx->opt_fir != 1 && var.t1_ok && !ctx->cur_skip_t1 && tmp_depth_of(d) <= H2Y_FIR_INT_MAX_DEPTH) {
+        /* The FIR resampler in one pass (k_fir_fused): a wave's unit of work is (frame, segment of chroma rows, strip of
+         * 240 columns).  Segments: as few as give every wave of the chip a unit, never shorter than 64 rows (each cut
+         * costs six recomputed row pairs).  "auto" keeps short batches, which cannot fill the chip that way, on the
+         * two-pass form. */
+        const uint32_t wq = (uint32_t)d->width / 4u, h2 = (uint32_t)d->height / 2u;
+        const uint32_t ns = (wq + 59u) / 60u, gw = (uint32_t)ctx->n_cu * 16u;
+        const uint32_t max_seg = h2 / 64u > 0u ? h2 / 64u : 1u;
+        uint32_t want = (gw + (uint32_t)n * ns - 1u) / ((uint32_t)n * ns);
+        if (want > max_seg) want = max_seg;
+        if (want < 1u) want = 1u;
+        const uint32_t seg_rows = (h2 + want - 1u) / want, nseg = (h2 + seg_rows - 1u) / seg_rows;
+        const uint64_t units = (uint64_t)n * ns * nseg;
+        if (ctx->opt_fir == 2 || 2u * units >= gw) {
+            const bool ident = var.pipe == 4 || var.pipe == 3; /* assumed floor 0 / ceiling 1 (pipe 3: half input, the table kernel's case) */
+            const uint32_t upf = ns * nseg;
+            ctx->last_was_t1 = true;
+            bool on_device = ctx->dev_frames.size() == ctx->frames_cap;
+            if (!on_device) ctx->dev_frames.assign(ctx->frames_cap, frame_io{});
+            for (int i = 0; i < n; i++) {
+                const size_t idx = (size_t)ctx->slot_base + i;
+                on_device = on_device && memcmp(&ctx->dev_frames[idx], &frames[i], sizeof(frame_io)) == 0;
+                ctx->h_frames[idx] = frames[i];
+            }
+            if (!on_device) {
+                HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frames + ctx->slot_base, ctx->h_frames + ctx->slot_base, n * sizeof(frame_io), hipMemcpyHostToDevice, ctx->stream));
+                for (int i = 0; i < n; i++) ctx->dev_frames[(size_t)ctx->slot_base + i] = ctx->h_frames[(size_t)ctx->slot_base + i];
+            }
+            int rc = ensure(ctx, ctx->d_partial, ctx->partial_cap, (size_t)n * upf * 6 * sizeof(float));
+            if (rc) return rc;
+            rc = ensure(ctx, ctx->d_redo, ctx->redo_cap, (size_t)n * upf * sizeof(uint32_t));
+            if (rc) return rc;
+            if (ident) {
+                const size_t need = (size_t)(n > 64 ? n : 64) * sizeof(uint32_t);
+                if (ctx->low_cap < need) {
+                    rc = ensure(ctx, ctx->d_low, ctx->low_cap, need);
+                    if (rc) return rc;
+                    HIP_TRY(ctx, hipMemsetAsync(ctx->d_low, 0, need, ctx->stream));
+                }
+            }
+            if (check) ctx->approx_min = ident;
+            firf_args fa;
+            fa.frames = ctx->d_frames + ctx->slot_base;
+            fa.n_frames = n;
+            fa.width = (uint32_t)d->width;
+            fa.height = (uint32_t)d->height;
+            fa.wq = wq;
+            fa.n_strips = ns;
+            fa.n_seg = nseg;
+            fa.seg_rows = seg_rows;
+            fa.units_per_frame = upf;
+            fa.total_units = (uint32_t)units;
+            fa.table = ctx->d_table;
+            fa.table1 = ctx->d_table1;
+            fa.sn = sn;
+            fa.partial = ctx->d_partial;
+            fa.redo_count = ctx->d_redo;
+            fa.low_flag = ident ? ctx->d_low : nullptr;
+            fa.assumed = d_assumed;
+            fa.pp = pp;
+            const uint32_t blocks_needed = (uint32_t)((units + 15u) / 16u);
+            const int grid = (int)(blocks_needed < (uint32_t)ctx->n_cu ? blocks_needed : (uint32_t)ctx->n_cu);
+            const bool ev = time_it && ctx->n_ev < kMaxEvents;
+            if (ev) {
+                HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->n_ev][0], ctx->stream));
+                ctx->last_name = "k_fir_fused";
+                char buf[192];
+                snprintf(buf, sizeof buf, "k_fir_fused<%s,420FIR,%s,%s> strips=%u segments=%u rows=%u", var.in_kind == H2Y_IN_F16 ? "F16" : "F32",
+                         var.mode == H2Y_MODE_YCBCR ? "YCBCR" : "YDZDX", ident ? "PQ_IDENT" : "PQ_NORM", ns, nseg, seg_rows);
+                ctx->last_variant = buf;
+            }
+            HIP_TRY(ctx, h2y_launch_fir_fused(var.in_kind, var.mode, ident, grid, ctx->stream, fa));
+            if (ev) {
+                HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->n_ev][1], ctx->stream));
+                ctx->n_ev++;
+            }
+            final_args fin;
+            fin.partial = ctx->d_partial;
+            fin.nblk = (int)upf;
+            fin.redo_count = ctx->d_redo;
+            fin.low_flag = ident ? ctx->d_low : nullptr;
+            fin.out = ctx->d_fstats + fstats_offset;
+            fin.is_u16 = 0;
+            fin.src_bit_depth = d->src_bit_depth;
+            fin.check = check ? 1 : 0;
+            fin.assumed = d_assumed;
+            fin.publish = nullptr;
+            fin.block_clock = nullptr;
+            fin.grid = 0;
+            fin.xcd_time = nullptr;
+            HIP_TRY(ctx, h2y_launch_stats_final(n, ctx->stream, fin));
+            return 0;
+        }
     }
     const geom g = make_geom(d, h2y_fused_threads(var), var.cols8 ? 8 : 4);
     const size_t npix = (size_t)d->width * d->height;

@@ -1,0 +1,356 @@
+/*
+ * h2y_device.h -- device-side helpers shared by the kernel translation units (h2y_kernels.hip,
+ * h2y_fir_fused.hip): wave reductions, pic_stats' min/max accumulators, global-address-space loads and
+ * stores, the sample loaders of the three input types, the exact tiers of one pixel, table staging.
+ * Device code only; included after <hip/hip_runtime.h>, h2y_math.h and h2y_kernels.h.
+ */
+#ifndef H2Y_DEVICE_H
+#define H2Y_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "h2y_kernels.h"
+#include "h2y_math.h"
+
+using namespace h2y;
+
+#define WAVE 64
+
+/* ---- wave reductions (DPP via __shfl_xor on 64 lanes) ------------------- */
+__device__ __forceinline__ float wave_min(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, WAVE));
+    return v;
+}
+
+/* pic_stats update, common.cpp:126-127: "s < min ? s : min" -- a NaN never
+ * wins, which v_min/v_max reproduce (they return the non-NaN operand).
+ * v_min3/v_max3 fold two new samples per instruction. */
+__device__ __forceinline__ float min3f(float a, float b, float c)
+{
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float max3f(float a, float b, float c)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+struct mm6 {
+    float lo[3], hi[3];
+    __device__ __forceinline__ void reset()
+    {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            lo[c] = 3.402823466e+38f; /* numeric_limits<float>::max(), common.cpp:118 */
+            hi[c] = 1.175494351e-38f; /* numeric_limits<float>::min(), common.cpp:119 */
+        }
+    }
+    __device__ __forceinline__ void add(int c, float s)
+    {
+        lo[c] = min3f(lo[c], s, s);
+        hi[c] = max3f(hi[c], s, s);
+    }
+    __device__ __forceinline__ void add2(int c, float s, float t)
+    {
+        lo[c] = min3f(lo[c], s, t);
+        hi[c] = max3f(hi[c], s, t);
+    }
+    __device__ __forceinline__ void add2_max(int c, float s, float t) { hi[c] = max3f(hi[c], s, t); }
+    /* the eight samples of one tile and channel: their own min/max come back too */
+    __device__ __forceinline__ void add8(int c, const float (&p)[4], const float (&q)[4], float &tlo, float &thi)
+    {
+        tlo = min3f(min3f(p[0], p[1], p[2]), min3f(p[3], q[0], q[1]), min3f(q[2], q[3], q[3]));
+        thi = max3f(max3f(p[0], p[1], p[2]), max3f(p[3], q[0], q[1]), max3f(q[2], q[3], q[3]));
+        lo[c] = min3f(lo[c], tlo, tlo);
+        hi[c] = max3f(hi[c], thi, thi);
+    }
+};
+
+/* Block-wide reduce of a thread's mm6 and one plain store of the six floats
+ * by thread 0.  All threads of the block must call it. */
+template <int NWAVES>
+__device__ __forceinline__ void block_store_mm(mm6 &m, float *smem /* NWAVES*6 */, float *dst)
+{
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float a = wave_min(m.lo[c]), b = wave_max(m.hi[c]);
+        if (lane == 0) {
+            smem[wave * 6 + 2 * c] = a;
+            smem[wave * 6 + 2 * c + 1] = b;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        float v = smem[threadIdx.x];
+        const bool is_max = threadIdx.x & 1;
+        for (int w = 1; w < NWAVES; w++) {
+            float o = smem[w * 6 + threadIdx.x];
+            v = is_max ? fmaxf(v, o) : fminf(v, o);
+        }
+        dst[threadIdx.x] = v;
+    }
+    __syncthreads();
+}
+
+/* Same, but per wave and with no barrier: the fused kernels' waves drift apart across
+ * frames instead of draining the CU's memory pipeline at every frame boundary.
+ * dst points at this wave's six floats; k_stats_final folds grid * waves entries. */
+__device__ __forceinline__ void wave_store_mm(mm6 &m, float *dst)
+{
+    const int lane = threadIdx.x & (WAVE - 1);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float a = wave_min(m.lo[c]), b = wave_max(m.hi[c]);
+        if (lane == 0) {
+            dst[2 * c] = a;
+            dst[2 * c + 1] = b;
+        }
+    }
+}
+
+/* ---- sample loads ------------------------------------------------------- */
+/* Picture planes are addressed as GLOBAL memory, not through flat pointers: a flat load counts on
+ * the LDS counter as well (every table read would wait for the prefetched tile), and a global
+ * load takes a uniform base in scalar registers plus a 32-bit lane offset.  The plane pointers of
+ * a frame come out of memory, so the compiler cannot know either fact by itself. */
+#define H2Y_GLOBAL __attribute__((address_space(1)))
+/* index counts T's; with a 32-bit index the BYTE offset is formed in 32 bits too (pictures are
+ * limited to 2^28 samples), which is what lets the lane offset stay one register */
+template <typename T> __device__ __forceinline__ T gload(const void *base, uint32_t index)
+{
+    return *(const H2Y_GLOBAL T *)((const H2Y_GLOBAL char *)base + index * (uint32_t)sizeof(T));
+}
+template <typename T> __device__ __forceinline__ T gload(const void *base, size_t index)
+{
+    return *((const H2Y_GLOBAL T *)base + index);
+}
+template <typename T> __device__ __forceinline__ void gstore(void *base, uint32_t index, T v)
+{
+    *(H2Y_GLOBAL T *)((H2Y_GLOBAL char *)base + index * (uint32_t)sizeof(T)) = v;
+}
+/* Picture samples are read once and output bytes written once per launch: non-temporal ("nt") accesses
+ * keep them from displacing each other in the caches (-1.5 % on C2, both together; either alone: nothing).
+ * Not for the 4:4:4 chroma scratch of the FIR path, which k_fir420 reads back. */
+#ifndef H2Y_NT
+#define H2Y_NT 3 /* 1: picture loads, 2: output stores, 3: both, 0: neither (A/B timing) */
+#endif
+template <typename T> __device__ __forceinline__ T gload_nt(const void *base, uint32_t index)
+{
+#if H2Y_NT & 1
+    return __builtin_nontemporal_load((const H2Y_GLOBAL T *)((const H2Y_GLOBAL char *)base + index * (uint32_t)sizeof(T)));
+#else
+    return gload<T>(base, index);
+#endif
+}
+template <typename T> __device__ __forceinline__ void gstore_nt(void *base, uint32_t index, T v)
+{
+#if H2Y_NT & 2
+    __builtin_nontemporal_store(v, (H2Y_GLOBAL T *)((H2Y_GLOBAL char *)base + index * (uint32_t)sizeof(T)));
+#else
+    gstore<T>(base, index, v);
+#endif
+}
+/* a pointer every lane holds the same value of, moved to scalar registers */
+template <typename P> __device__ __forceinline__ P *uniform_ptr(P *p)
+{
+    const uint64_t v = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return reinterpret_cast<P *>(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ frame_io uniform_io(const frame_io *p)
+{
+    frame_io io = *p;
+#pragma unroll
+    for (int c = 0; c < 3; c++) io.in[c] = uniform_ptr(io.in[c]);
+    io.out = uniform_ptr(io.out);
+    io.tmp_cb = uniform_ptr(io.tmp_cb);
+    io.tmp_cr = uniform_ptr(io.tmp_cr);
+    return io;
+}
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <int KIND> struct in_traits;
+template <> struct in_traits<H2Y_IN_F32> {
+    typedef float T;
+    /* i: sample index, a multiple of 4 (16-byte aligned planes) */
+    template <typename I> static __device__ __forceinline__ void load4(const void *p, I i, float v[4]) { load4q(p, i >> 2, v); }
+    /* q: quad index (sample index / 4) */
+    template <typename I> static __device__ __forceinline__ void load4q(const void *p, I q4, float v[4])
+    {
+        const f32x4 q = gload_nt<f32x4>(p, (uint32_t)q4);
+        v[0] = q.x; v[1] = q.y; v[2] = q.z; v[3] = q.w;
+    }
+    template <typename I> static __device__ __forceinline__ float load1(const void *p, I i) { return gload<float>(p, i); }
+};
+template <> struct in_traits<H2Y_IN_F16> {
+    typedef _Float16 T;
+    template <typename I> static __device__ __forceinline__ void load4(const void *p, I i, float v[4]) { load4q(p, i >> 2, v); }
+    template <typename I> static __device__ __forceinline__ void load4q(const void *p, I q4, float v[4])
+    {
+        /* exr.cpp:233-235: half widened to float, exact */
+        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+        const h4 q = gload_nt<h4>(p, (uint32_t)q4);
+        v[0] = (float)q.x; v[1] = (float)q.y; v[2] = (float)q.z; v[3] = (float)q.w;
+    }
+    template <typename I> static __device__ __forceinline__ float load1(const void *p, I i) { return (float)gload<_Float16>(p, i); }
+};
+template <> struct in_traits<H2Y_IN_U16> {
+    typedef uint16_t T;
+    template <typename I> static __device__ __forceinline__ void load4(const void *p, I i, float v[4]) { load4q(p, i >> 2, v); }
+    template <typename I> static __device__ __forceinline__ void load4q(const void *p, I q4, float v[4])
+    {
+        /* convert.cpp:989-994: (float) of the unsigned short */
+        const u32x2 q = gload_nt<u32x2>(p, (uint32_t)q4);
+        v[0] = (float)(q.x & 0xFFFFu); v[1] = (float)(q.x >> 16);
+        v[2] = (float)(q.y & 0xFFFFu); v[3] = (float)(q.y >> 16);
+    }
+    template <typename I> static __device__ __forceinline__ float load1(const void *p, I i) { return (float)gload<uint16_t>(p, i); }
+};
+
+/* ---- one pixel: normalise -> PQ -> scale -> matrix ---------------------- */
+
+/* Careful tier for one pixel: the reference's operations one by one (double-
+ * double pow in place of libm's, IEEE divisions).  Out of line: about one
+ * pixel in 10^4 comes here. */
+struct ycc {
+    uint32_t y, cb, cr;
+};
+template <int MODE>
+__device__ __attribute__((noinline)) ycc pixel_careful(const pix_params *spp /* block's copy in LDS */, float G, float B, float R)
+{
+    const pix_params &pp = *spp;
+    ycc o;
+    uint32_t &Y = o.y, &Cb = o.cb, &Cr = o.cr;
+    if (pp.convert_transfer) {
+        /* convert.cpp:1024-1109: source transfer -> linear -> destination transfer, then the scale step */
+        G = pix_scale(tf_from_linear(pp.dst_tf, tf_to_linear(pp.src_tf, G)), pp.mulY, pp.addY);
+        B = pix_scale(tf_from_linear(pp.dst_tf, tf_to_linear(pp.src_tf, B)), pp.mulC, pp.addC);
+        R = pix_scale(tf_from_linear(pp.dst_tf, tf_to_linear(pp.src_tf, R)), pp.mulC, pp.addC);
+    }
+    bool dummy;
+    pix_matrix<MODE, true>(pp, G, B, R, Y, Cb, Cr, &dummy);
+    return o;
+}
+
+/* PIPE: what is known at compile time about the front of the pixel pipeline */
+#define H2Y_PIPE_RUNTIME 0  /* read pp.convert_transfer / pp.norm_identity */
+#define H2Y_PIPE_PQ_IDENT 1 /* LINEAR -> PQ, floor 0 / ceiling 1: no normalisation arithmetic */
+#define H2Y_PIPE_PQ_NORM 2  /* LINEAR -> PQ with (x - offset) / range */
+#define H2Y_PIPE_NONE 6     /* equal transfers: the samples go to the matrix as they are (k_fused2 only) */
+
+/* normalisation of one sample, convert.cpp:1017-1019: binary32 subtract, IEEE divide */
+template <int PIPE> __device__ __forceinline__ float norm1(const pix_params &pp, int c, float v)
+{
+    const bool conv = PIPE == H2Y_PIPE_RUNTIME ? pp.convert_transfer != 0 : true;
+    const bool ident = PIPE == H2Y_PIPE_RUNTIME ? pp.norm_identity : PIPE == H2Y_PIPE_PQ_IDENT;
+    return (conv && !ident) ? (v - pp.offset[c]) / pp.range[c] : v;
+}
+
+/* fast tier of one pixel (inputs normalised).  Returns true when the result
+ * cannot be trusted and pixel_careful() must be used instead. */
+template <int MODE, int PIPE>
+__device__ __forceinline__ bool pixel_fast(const pix_params &pp, const pq_recA *sA, const pq_recB *sB, float G, float B, float R,
+                                           uint32_t &Y, uint32_t &Cb, uint32_t &Cr)
+{
+    const bool conv = PIPE == H2Y_PIPE_RUNTIME ? pp.convert_transfer != 0 : true;
+    float g = G, b = B, r = R;
+    bool unsure = false;
+    if (PIPE == H2Y_PIPE_RUNTIME && pp.convert_transfer == 2) {
+        Y = Cb = Cr = 0;
+        return true; /* no fast tier for this transfer pair */
+    }
+    if (conv) {
+        bool sg, sb, sr;
+        g = pix_scale(pq_fast(G, sA, sB, &sg), pp.mulY, pp.addY);
+        b = pix_scale(pq_fast(B, sA, sB, &sb), pp.mulC, pp.addC);
+        r = pix_scale(pq_fast(R, sA, sB, &sr), pp.mulC, pp.addC);
+        unsure = sg | sb | sr;
+    }
+    bool um;
+    pix_matrix<MODE, false>(pp, g, b, r, Y, Cb, Cr, &um);
+    return unsure | um;
+}
+
+/* one pixel, both tiers (used by the narrow-width kernel) */
+template <int MODE>
+__device__ __forceinline__ void pixel(const pix_params &pp, const pix_params *spp, const pq_recA *sA, const pq_recB *sB,
+                                      float G, float B, float R, uint32_t &Y, uint32_t &Cb, uint32_t &Cr)
+{
+    G = norm1<H2Y_PIPE_RUNTIME>(pp, 0, G);
+    B = norm1<H2Y_PIPE_RUNTIME>(pp, 1, B);
+    R = norm1<H2Y_PIPE_RUNTIME>(pp, 2, R);
+    if (__builtin_expect(pixel_fast<MODE, H2Y_PIPE_RUNTIME>(pp, sA, sB, G, B, R, Y, Cb, Cr), 0)) {
+        const ycc o = pixel_careful<MODE>(spp, G, B, R);
+        Y = o.y;
+        Cb = o.cb;
+        Cr = o.cr;
+    }
+}
+
+/* convert.cpp:939-940: range = ceiling - floor (int), offset = floor, as float */
+__device__ __forceinline__ pix_params with_assumed(const pix_params &in, const assumed_stats *as)
+{
+    pix_params pp = in;
+    bool ident = true;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const int fl = as->floor_[c], ce = as->ceil_[c];
+        pp.offset[c] = (float)fl;
+        pp.range[c] = (float)(ce - fl);
+        ident = ident && fl == 0 && (ce - fl) == 1;
+    }
+    pp.norm_identity = ident ? 1 : 0;
+    return pp;
+}
+
+/* unsigned divide by a launch constant: q = n / d via a 32-bit reciprocal */
+__device__ __forceinline__ uint32_t udiv_magic(uint32_t n, uint32_t d, uint32_t magic, uint32_t &rem)
+{
+    uint32_t q = __umulhi(n, magic);
+    uint32_t r = n - q * d;
+    if (r >= d) {
+        q++;
+        r -= d;
+    }
+    rem = r;
+    return q;
+}
+
+/* N 16-byte records from global memory to LDS: every load of a thread is issued before the first is
+ * stored (as a plain loop the copy is one memory round trip per iteration -- ten of them, 10-15 us, at the
+ * head of every launch of the first-tier kernel) */
+template <int THREADS, int N> __device__ __forceinline__ void stage16(const void *src, void *dst)
+{
+    constexpr int IT = (N + THREADS - 1) / THREADS;
+    const uint4 *g = reinterpret_cast<const uint4 *>(src);
+    uint4 *l = reinterpret_cast<uint4 *>(dst);
+    uint4 r[IT];
+#pragma unroll
+    for (int j = 0; j < IT; j++) {
+        const int i = threadIdx.x + j * THREADS;
+        if (j < IT - 1 || i < N) r[j] = g[i];
+    }
+#pragma unroll
+    for (int j = 0; j < IT; j++) {
+        const int i = threadIdx.x + j * THREADS;
+        if (j < IT - 1 || i < N) l[i] = r[j];
+    }
+}
+template <int THREADS> __device__ __forceinline__ void stage_table(const void *table, pq_recA *s_tab)
+{
+    stage16<THREADS, 2 * H2Y_PQ_NREC>(table, s_tab);
+}
+
+#endif /* H2Y_DEVICE_H */

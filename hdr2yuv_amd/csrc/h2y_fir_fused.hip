@@ -1,0 +1,271 @@
+/*
+ * h2y_fir_fused.hip -- k_fir_fused: the whole path with the FIR chroma resampler in ONE pass.
+ *
+ *   pic_stats min/max + matrix_convert (convert.cpp:879-1221) + Subsample444to420_FIR (convert.cpp:261-383)
+ *   + write_yuv's clamp (tiff.cpp:457-550): planar float RGB in, .yuv 4:2:0 out, nothing in between touches HBM.
+ *
+ * The two-pass form (fused kernel -> 4:4:4 Cb/Cr scratch -> k_fir420) moves 23 bytes per pixel against 15
+ * algorithmic.  Here the 4:4:4 chroma never leaves the registers:
+ *
+ *   A WAVE owns a column strip of 240 picture columns and walks it top to bottom, one row pair per step; lane L
+ *   holds columns 4L-8 .. 4L-5 of the strip (lanes 0, 1 and 62, 63 are halo: they recompute the neighbour strips'
+ *   pixels -- 6 % -- so that no wave ever waits for another).
+ *   Horizontal 7-tap (even columns): the taps at odd columns come from lanes L-2, L-1, L+1 by three DPP wave shifts
+ *   of one packed dword per row and plane.
+ *   Vertical 12-tap: each lane keeps the last eleven rows of ITS two 4:2:2 columns (both planes: 22 registers) and
+ *   emits chroma row j = s - 3 at step s.  Picture edges replicate as the reference's index clamps do: rows above
+ *   the picture are row 0 (the history is filled with it at step 0), rows below are the last row (three virtual
+ *   steps), the first and last column stand in for the columns beyond them.
+ *   A frame's strip is cut into segments of rows so that a launch has enough waves' worth of work; a segment that
+ *   starts inside the picture first recomputes the three row pairs above it (and the one before it three below):
+ *   6 row pairs per cut.
+ *
+ * Arithmetic: the binary32 first tier (pq_t1 + pix_matrix_t1) for every pixel; where a lane's pixel is not settled
+ * by it (unsure sample near a rounding boundary, sample outside the table: 0.05 % of pixels at 12 bits, every pixel
+ * of a black bar) the wave takes the binary64 tier for that pixel position on the spot -- the FIR consumes the
+ * 4:4:4 values at once, so there is no "provisional bytes now, exact bytes later" here.  Both tables sit in LDS
+ * (100 KB + 50 KB), one block of 1024 threads per CU.  The FIR stages run in integers (fir_h_int / fir_v_int:
+ * equal to the reference's float expressions for code values up to 14 bits, tools/fir_int_check.cpp).
+ *
+ * The loop body keeps k_fused_t1's discipline: global memory operations in a fixed order, none inside a branch
+ * (lanes that own no chroma store lane 2's sample again, rows not yet final go to the segment's first row and are
+ * overwritten in order by the same lane), so every s_waitcnt is exact and the next step's rows arrive while this
+ * step computes.
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "h2y_device.h"
+
+#define FF_THREADS 1024
+#define FF_OWN_LANES 60 /* lanes 2 .. 61 own chroma: 240 picture columns per strip */
+
+struct ff_rows { /* one row pair of the lane's four columns, three planes */
+    float g0[4], b0[4], r0[4], g1[4], b1[4], r1[4];
+};
+
+/* lane L gets lane L-1's / L+1's value (DPP wave shifts; what arrives in lane 0 resp. 63 is never used) */
+__device__ __forceinline__ uint32_t from_lane_below(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false); }
+__device__ __forceinline__ uint32_t from_lane_above(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xF, 0xF, false); }
+
+struct ff_edges { /* per lane, fixed for a unit */
+    bool any;    /* the wave holds a picture edge (uniform) */
+    bool left0;  /* this lane's columns are the picture's first four */
+    bool left1;  /* ... the next four */
+    bool right0; /* ... the last four */
+};
+
+/* Horizontal stage for one row and plane (convert.cpp:291-320): c[0..3] = this lane's four 4:4:4 values; returns
+ * the two 4:2:2 values at its even columns (column 4L | column 4L+2 << 16), clamped to [0, maxCV] and truncated. */
+__device__ __forceinline__ uint32_t ff_hstage(const uint32_t (&c)[4], const ff_edges &e, int32_t maxcv)
+{
+    const uint32_t p13 = c[1] | (c[3] << 16);
+    uint32_t l1 = from_lane_below(p13); /* columns 4L-3, 4L-1 */
+    uint32_t l2 = from_lane_below(l1);  /* columns 4L-7, 4L-5 */
+    uint32_t r1 = from_lane_above(p13); /* columns 4L+5, 4L+7 */
+    if (e.any) { /* the reference's "picture border logic": indices below 0 read column 0, beyond width-1 the last column */
+        const uint32_t c0_below = from_lane_below(c[0]);
+        const uint32_t own0 = c[0] | (c[0] << 16), own3 = c[3] | (c[3] << 16);
+        l1 = e.left0 ? own0 : l1;
+        l2 = e.left0 ? own0 : (e.left1 ? (c0_below << 16) : l2); /* 4L-5 = -1 -> column 0, which is the lane below's c[0] */
+        r1 = e.right0 ? own3 : r1;
+    }
+    const int32_t l1lo = (int32_t)(l1 & 0xFFFFu), l1hi = (int32_t)(l1 >> 16), l2hi = (int32_t)(l2 >> 16);
+    const int32_t r1lo = (int32_t)(r1 & 0xFFFFu), r1hi = (int32_t)(r1 >> 16);
+    const int32_t c0 = (int32_t)c[0], c1 = (int32_t)c[1], c2 = (int32_t)c[2], c3 = (int32_t)c[3];
+    /* even column i = 4L:   taps i-5 .. i+5 = (4L-5, 4L-3, 4L-1, 4L, 4L+1, 4L+3, 4L+5) */
+    const uint32_t a = fir_h_int(l2hi, l1lo, l1hi, c0, c1, c3, r1lo, maxcv);
+    /* even column i = 4L+2: (4L-3, 4L-1, 4L+1, 4L+2, 4L+3, 4L+5, 4L+7) */
+    const uint32_t b = fir_h_int(l1lo, l1hi, c1, c2, c3, r1lo, r1hi, maxcv);
+    return a | (b << 16);
+}
+
+/* Vertical stage (convert.cpp:323-376) for both of the lane's 4:2:2 columns: h[0..10] = rows 2j-5 .. 2j+5, n0 = row
+ * 2j+6; then write_yuv's chroma clamp (its range lies inside [0, maxCV], so one clamp does both). */
+__device__ __forceinline__ uint32_t ff_vstage(const uint32_t (&h)[11], uint32_t n0, int32_t clo, int32_t chi)
+{
+    uint32_t o[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+#define FFV(x) ((int32_t)(k ? (x) >> 16 : (x) & 0xFFFFu))
+        o[k] = fir_v_int(FFV(h[0]), FFV(h[1]), FFV(h[2]), FFV(h[3]), FFV(h[4]), FFV(h[5]), FFV(h[6]), FFV(h[7]), FFV(h[8]), FFV(h[9]), FFV(h[10]),
+                         FFV(n0), clo, chi);
+#undef FFV
+    }
+    return o[0] | (o[1] << 16);
+}
+
+template <int IN_KIND, int MODE, int PIPE>
+__global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
+{
+    __shared__ pq_rec1 s_t1[H2Y_T1_NREC];
+    __shared__ pq_recA s_t2[2 * H2Y_PQ_NREC]; /* A records, then B records */
+    __shared__ pix_params s_pp;
+    const pq_recA *sA = s_t2;
+    const pq_recB *sB = reinterpret_cast<const pq_recB *>(s_t2 + H2Y_PQ_NREC);
+    stage16<FF_THREADS, H2Y_T1_NREC>(a.table1, s_t1);
+    stage_table<FF_THREADS>(a.table, s_t2);
+    const pix_params pp = with_assumed(a.pp, a.assumed);
+    t1_sens sn = a.sn;
+    asm volatile("" : "+v"(sn.a_lo), "+v"(sn.a_hi));
+    if (threadIdx.x == 0) s_pp = pp;
+    __syncthreads();
+
+    typedef in_traits<IN_KIND> IN;
+    const uint32_t lane = threadIdx.x & (WAVE - 1);
+    const uint32_t GW = gridDim.x * (FF_THREADS / WAVE);
+    const uint32_t gw = __builtin_amdgcn_readfirstlane(blockIdx.x * (FF_THREADS / WAVE) + threadIdx.x / WAVE); /* uniform, and known to be */
+    const uint32_t W = a.width, H = a.height, WQ = a.wq, H2 = H >> 1;
+    const uint32_t npix = W * H, ncb = (W >> 1) * (H >> 1);
+    const int32_t maxcv = (int32_t)pp.maxCV, clo = (int32_t)pp.clo_s, chi = (int32_t)pp.chi_s; /* float input: down_shift == 0 */
+
+    /* a wave's units: u = gw, gw + GW, ...; unit = (frame, segment, strip), strips of one band next to each other
+     * so that the sixteen waves of a block fill whole lines of the output between them */
+    for (uint32_t u = gw; u < a.total_units; u += GW) {
+        const uint32_t f = u / a.units_per_frame, r = u - f * a.units_per_frame;
+        const uint32_t seg = r / a.n_strips, strip = r - seg * a.n_strips;
+        const frame_io io = uniform_io(a.frames + f);
+        const uint32_t j0 = seg * a.seg_rows, j1 = umin32(j0 + a.seg_rows, H2);   /* chroma rows [j0, j1) are this unit's */
+        const uint32_t s_begin = j0 >= 3u ? j0 - 3u : 0u, s_end = j1 + 2u;          /* steps: row pairs s_begin .. s_end (those >= H2 are virtual) */
+        const int32_t qxu = (int32_t)(FF_OWN_LANES * strip + lane) - 2;             /* this lane's quad column, before clamping */
+        const uint32_t qx = (uint32_t)min(max(qxu, 0), (int32_t)WQ - 1);
+        const bool own = lane >= 2u && lane < 2u + FF_OWN_LANES && qxu < (int32_t)WQ;
+        ff_edges e;
+        e.any = strip == 0u || strip + 1u == a.n_strips;
+        e.left0 = qxu == 0;
+        e.left1 = qxu == 1;
+        e.right0 = qxu == (int32_t)WQ - 1;
+
+        mm6 mm;
+        mm.reset();
+        uint32_t flagged = 0; /* pixels the first tier could not settle (uniform) */
+        uint64_t low_m = 0;   /* lanes that met a sample <= -1 (see k_fused_t1: the minimum is only sampled) */
+        uint32_t hcb[11], hcr[11]; /* rows 2s-11 .. 2s-1 of the 4:2:2 intermediate, this lane's two columns */
+#pragma unroll
+        for (int k = 0; k < 11; k++) hcb[k] = hcr[k] = 0u;
+
+        ff_rows v; /* the row pair in hand; refilled row by row with the next one */
+        uint32_t q0 = 2u * umin32(s_begin, H2 - 1u) * WQ + qx;
+        IN::load4q(io.in[0], q0, v.g0); IN::load4q(io.in[1], q0, v.b0); IN::load4q(io.in[2], q0, v.r0);
+        IN::load4q(io.in[0], q0 + WQ, v.g1); IN::load4q(io.in[1], q0 + WQ, v.b1); IN::load4q(io.in[2], q0 + WQ, v.r1);
+#pragma unroll
+        for (int j = 0; j < 4; j++) asm volatile("" ::"v"(v.g0[j]), "v"(v.b0[j]), "v"(v.r0[j]), "v"(v.g1[j]), "v"(v.b1[j]), "v"(v.r1[j]));
+
+        for (uint32_t s = s_begin; s <= s_end; s++) {
+            const uint32_t q0n = 2u * umin32(s + 1u, H2 - 1u) * WQ + qx; /* the next step's rows (the last rows again once the picture ends) */
+            uint32_t yp[2][2], n_cb[2], n_cr[2];
+#pragma unroll
+            for (int row = 0; row < 2; row++) {
+                const float(&gv)[4] = row ? v.g1 : v.g0;
+                const float(&bv)[4] = row ? v.b1 : v.b0;
+                const float(&rv)[4] = row ? v.r1 : v.r0;
+                if (PIPE == H2Y_PIPE_PQ_IDENT) { /* as k_fused_t1: every sample's maximum, a subsample of the minimum */
+                    if (row == 0) { mm.add2(0, gv[0], gv[1]); mm.add2(1, bv[0], bv[1]); mm.add2(2, rv[0], rv[1]); }
+                    else { mm.add2_max(0, gv[0], gv[1]); mm.add2_max(1, bv[0], bv[1]); mm.add2_max(2, rv[0], rv[1]); }
+                    mm.add2_max(0, gv[2], gv[3]); mm.add2_max(1, bv[2], bv[3]); mm.add2_max(2, rv[2], rv[3]);
+                } else {
+                    mm.add2(0, gv[0], gv[1]); mm.add2(0, gv[2], gv[3]);
+                    mm.add2(1, bv[0], bv[1]); mm.add2(1, bv[2], bv[3]);
+                    mm.add2(2, rv[0], rv[1]); mm.add2(2, rv[2], rv[3]);
+                }
+                uint32_t Y[4], Cb[4], Cr[4];
+#pragma unroll
+                for (int col = 0; col < 4; col++) {
+                    const float Gn = norm1<PIPE>(pp, 0, gv[col]), Bn = norm1<PIPE>(pp, 1, bv[col]), Rn = norm1<PIPE>(pp, 2, rv[col]);
+                    const pq_rec1 cg = pq_t1_fetch(Gn, s_t1), cb = pq_t1_fetch(Bn, s_t1), cr = pq_t1_fetch(Rn, s_t1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    bool ug, ub, ur;
+                    const float g = pix_scale(pq_t1_eval(Gn, cg, &ug), pp.mulY, pp.addY);
+                    const float b = pix_scale(pq_t1_eval(Bn, cb, &ub), pp.mulC, pp.addC);
+                    const float rr = pix_scale(pq_t1_eval(Rn, cr, &ur), pp.mulC, pp.addC);
+                    bool ra, rb;
+                    pix_matrix_t1<MODE>(pp, sn, g, b, rr, ug | ub | ur, Y[col], Cb[col], Cr[col], &ra, &rb);
+                    const uint64_t fm = __builtin_amdgcn_ballot_w64(ra) | __builtin_amdgcn_ballot_w64(rb);
+                    if (__builtin_expect(fm != 0, 0)) {
+                        /* some lane's pixel here is not settled: the binary64 tier for this pixel position, all lanes
+                         * together (no memory operation in this branch but LDS reads) */
+                        uint32_t Y2, Cb2, Cr2;
+                        const bool fl = ((fm >> lane) & 1u) != 0;
+                        const bool un = pixel_fast<MODE, PIPE>(pp, sA, sB, Gn, Bn, Rn, Y2, Cb2, Cr2);
+                        if (__builtin_expect(fl & un, 0)) {
+                            const ycc k = pixel_careful<MODE>(&s_pp, Gn, Bn, Rn);
+                            Y2 = k.y; Cb2 = k.cb; Cr2 = k.cr;
+                        }
+                        Y[col] = fl ? Y2 : Y[col];
+                        Cb[col] = fl ? Cb2 : Cb[col];
+                        Cr[col] = fl ? Cr2 : Cr[col];
+                        flagged += (uint32_t)__popcll(fm);
+                        if (PIPE == H2Y_PIPE_PQ_IDENT) low_m |= __builtin_amdgcn_ballot_w64(fl && min3f(Gn, Bn, Rn) <= -1.0f);
+                    }
+                }
+                yp[row][0] = pix_yuv_clamp<true>(pp, Y[0], false) | (pix_yuv_clamp<true>(pp, Y[1], false) << 16);
+                yp[row][1] = pix_yuv_clamp<true>(pp, Y[2], false) | (pix_yuv_clamp<true>(pp, Y[3], false) << 16);
+                n_cb[row] = ff_hstage(Cb, e, maxcv);
+                n_cr[row] = ff_hstage(Cr, e, maxcv);
+                if (row == 0) { /* row 0 of the next step, into the registers just read for the last time */
+                    IN::load4q(io.in[0], q0n, v.g0);
+                    IN::load4q(io.in[1], q0n, v.b0);
+                    IN::load4q(io.in[2], q0n, v.r0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            gstore_nt<u32x2>(io.out, q0, u32x2{yp[0][0], yp[0][1]});
+            gstore_nt<u32x2>(io.out, q0 + WQ, u32x2{yp[1][0], yp[1][1]});
+            IN::load4q(io.in[0], q0n + WQ, v.g1);
+            IN::load4q(io.in[1], q0n + WQ, v.b1);
+            IN::load4q(io.in[2], q0n + WQ, v.r1);
+
+            if (s >= H2) { /* below the picture: both new rows are its last row (convert.cpp:337-347) */
+                n_cb[0] = n_cb[1] = hcb[10];
+                n_cr[0] = n_cr[1] = hcr[10];
+            }
+            if (s == 0u) { /* above the picture: row 0 (the same clamps) */
+#pragma unroll
+                for (int k = 0; k < 11; k++) { hcb[k] = n_cb[0]; hcr[k] = n_cr[0]; }
+            }
+            /* chroma row j = s - 3 from rows 2j-5 .. 2j+6 = history + the new row 2s.  Before the history is whole
+             * (j < j0) the value is not yet that row's: it goes to row j0, which this lane overwrites in order */
+            uint32_t ocb = ff_vstage(hcb, n_cb[0], clo, chi), ocr = ff_vstage(hcr, n_cr[0], clo, chi);
+            const uint32_t jj = (s >= j0 + 3u) ? s - 3u : j0;
+            uint32_t cidx = jj * WQ + qx; /* dword index in a chroma plane: two samples per quad column */
+            /* lanes that own no chroma column of this strip store lane 2's dword once more */
+            const uint32_t ocb2 = __builtin_amdgcn_readlane(ocb, 2), ocr2 = __builtin_amdgcn_readlane(ocr, 2), cidx2 = __builtin_amdgcn_readlane(cidx, 2);
+            ocb = own ? ocb : ocb2;
+            ocr = own ? ocr : ocr2;
+            cidx = own ? cidx : cidx2;
+            gstore_nt<uint32_t>(io.out, (npix >> 1) + cidx, ocb);
+            gstore_nt<uint32_t>(io.out, ((npix + ncb) >> 1) + cidx, ocr);
+#pragma unroll
+            for (int k = 0; k < 9; k++) { hcb[k] = hcb[k + 2]; hcr[k] = hcr[k + 2]; }
+            hcb[9] = n_cb[0]; hcb[10] = n_cb[1];
+            hcr[9] = n_cr[0]; hcr[10] = n_cr[1];
+            q0 = q0n;
+        }
+        /* drain the loads the last step asked for (their registers are reused by the next unit's first loads) */
+#pragma unroll
+        for (int j = 0; j < 4; j++) asm volatile("" ::"v"(v.g0[j]), "v"(v.b0[j]), "v"(v.r0[j]), "v"(v.g1[j]), "v"(v.b1[j]), "v"(v.r1[j]));
+        const size_t slot = (size_t)f * a.units_per_frame + r;
+        wave_store_mm(mm, a.partial + slot * 6);
+        if (lane == 0) {
+            a.redo_count[slot] = flagged >> 3; /* in tiles of eight pixels, the unit the host steers by */
+            if (PIPE == H2Y_PIPE_PQ_IDENT && a.low_flag && low_m != 0) a.low_flag[f] = 1u;
+        }
+    }
+}
+
+/* ---- launch ------------------------------------------------------------- */
+typedef void (*firf_fn)(firf_args);
+template <int IN_KIND> static firf_fn pick_firf(int mode, int pipe)
+{
+    if (mode == H2Y_MODE_YCBCR)
+        return pipe == H2Y_PIPE_PQ_IDENT ? k_fir_fused<IN_KIND, H2Y_MODE_YCBCR, H2Y_PIPE_PQ_IDENT> : k_fir_fused<IN_KIND, H2Y_MODE_YCBCR, H2Y_PIPE_PQ_NORM>;
+    return pipe == H2Y_PIPE_PQ_IDENT ? k_fir_fused<IN_KIND, H2Y_MODE_YDZDX, H2Y_PIPE_PQ_IDENT> : k_fir_fused<IN_KIND, H2Y_MODE_YDZDX, H2Y_PIPE_PQ_NORM>;
+}
+
+hipError_t h2y_launch_fir_fused(int in_kind, int mode, bool ident, int grid, hipStream_t st, const firf_args &a)
+{
+    const int pipe = ident ? H2Y_PIPE_PQ_IDENT : H2Y_PIPE_PQ_NORM;
+    firf_fn fn = in_kind == H2Y_IN_F16 ? pick_firf<H2Y_IN_F16>(mode, pipe) : pick_firf<H2Y_IN_F32>(mode, pipe);
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(FF_THREADS), 0, st, a);
+    return hipGetLastError();
+}

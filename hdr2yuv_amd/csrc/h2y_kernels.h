@@ -86,6 +86,7 @@ struct fused_variant {
                       6 equal transfers, no PQ at all (k_fused2) */
     bool narrow;   /* width % 4 != 0: scalar-load variant */
     bool even_h;   /* height % 2 == 0: the branch-free loop forms (k_fused2, k_fused_t1) apply */
+    bool t1_ok = false; /* the binary32 first tier applies to this descriptor (whatever pipe was chosen in the end): t1_sens is filled in */
     bool cols8 = false; /* k_fused_lut16 only: 8-column thread tiles (width % 8 == 0, all planes 16-byte aligned); wq and tiles count those */
 };
 
@@ -131,6 +132,25 @@ struct inverse_args {
     int shift, shift_right;
 };
 
+/* k_fir_fused (h2y_fir_fused.hip): a wave's unit of work is (frame, segment of chroma rows, strip of 240 columns) */
+struct firf_args {
+    const frame_io *frames;
+    int n_frames;
+    uint32_t width, height;
+    uint32_t wq;              /* width / 4 */
+    uint32_t n_strips;        /* ceil(wq / 60) */
+    uint32_t n_seg, seg_rows; /* segments per frame, chroma rows per segment (the last may be shorter) */
+    uint32_t units_per_frame; /* n_seg * n_strips */
+    uint32_t total_units;     /* n_frames * units_per_frame */
+    const void *table, *table1;
+    h2y::t1_sens sn;
+    float *partial;           /* [n_frames][units_per_frame][6] */
+    uint32_t *redo_count;     /* [n_frames][units_per_frame] */
+    uint32_t *low_flag;       /* [n_frames] or NULL (see fused_args) */
+    const assumed_stats *assumed;
+    h2y::pix_params pp;
+};
+
 struct up_args { /* k_up444: one or two chroma planes, (width/2 x height/2) -> (width x height) */
     const uint16_t *src0, *src1; /* src1 may be NULL (one plane) */
     uint16_t *dst0, *dst1;
@@ -152,6 +172,7 @@ hipError_t h2y_launch_stats(int in_kind, int grid, hipStream_t st, const stats_a
 hipError_t h2y_launch_stats_final(int n_frames, hipStream_t st, const final_args &a);
 hipError_t h2y_launch_fir420(hipStream_t st, const fir_args &a);
 hipError_t h2y_launch_inverse(int grid, hipStream_t st, const inverse_args &a);
+hipError_t h2y_launch_fir_fused(int in_kind, int mode, bool ident, int grid, hipStream_t st, const firf_args &a);
 hipError_t h2y_launch_up444(hipStream_t st, const up_args &a);
 hipError_t h2y_launch_box420(hipStream_t st, const uint16_t *src, uint16_t *dst, int W, int H);
 

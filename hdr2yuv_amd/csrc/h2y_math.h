@@ -1028,6 +1028,37 @@ H2Y_FN uint32_t fir_v(float m5, float m4, float m3, float m2, float m1, float m0
     return fir_clamp_trunc(acc + 0.5f, fmaxcv);
 }
 
+/* ---- the same two stages in integers, for code values up to 14 bits ------------------------------
+ * Every coefficient is k/512 and every sample an integer below 2^14, so each product, each partial sum and the
+ * final "+0.5" of fir_h() / fir_v() is a multiple of 2^-9 below 2^15 in magnitude (the positive taps add up to
+ * 616/512 and 628/512 of maxCV <= 16383: 19 711 and 20 095): all of them are exact in binary32, the float
+ * expression IS the integer S/512 + 1/2, and clamp-then-truncate is med3(floor((S + 256) / 512), 0, maxCV).
+ * (At 15 and 16 bits the sums pass 2^15 and round; the two-pass float form stays in charge there.)
+ * tools/fir_int_check.cpp compares the two forms (tests/test_pq_math.py). */
+H2Y_FN int32_t imed3(int32_t v, int32_t lo, int32_t hi)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    int32_t r;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
+    return r;
+#else
+    return v < lo ? lo : (v > hi ? hi : v);
+#endif
+}
+#define H2Y_FIR_INT_MAX_DEPTH 14
+H2Y_FN uint32_t fir_h_int(int32_t m5, int32_t m3, int32_t m1, int32_t c, int32_t p1, int32_t p3, int32_t p5, int32_t maxcv)
+{
+    const int32_t S = 21 * (m5 + p5) - 52 * (m3 + p3) + 159 * (m1 + p1) + 256 * c + 256;
+    return (uint32_t)imed3(S >> 9, 0, maxcv);
+}
+/* lo/hi: [0, maxCV] for the bare stage, or write_yuv's chroma range (inside [0, maxCV]) to fold that clamp in */
+H2Y_FN uint32_t fir_v_int(int32_t m5, int32_t m4, int32_t m3, int32_t m2, int32_t m1, int32_t m0, int32_t p1, int32_t p2, int32_t p3,
+                          int32_t p4, int32_t p5, int32_t p6, int32_t lo, int32_t hi)
+{
+    const int32_t S = 228 * (m0 + p1) + 70 * (m1 + p2) - 37 * (m2 + p3) - 21 * (m3 + p4) + 11 * (m4 + p5) + 5 * (m5 + p6) + 256;
+    return (uint32_t)imed3(S >> 9, lo, hi);
+}
+
 /* ---- Subsample420to444, convert.cpp:1869-1986 -----------------------------------------------
  * clamp to [lo, hi] and truncate (:1932-1934 and alike); t is never NaN (sums of finite samples) */
 H2Y_FN uint32_t up_clamp_trunc(float t, float lo, float hi)

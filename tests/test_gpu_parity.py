@@ -958,3 +958,48 @@ def test_inverse_420_flow(ctx, oracle):
             for c in range(3):
                 got = dout[c].cpu().numpy().view(np.uint16)
                 assert np.array_equal(got, want[c]), (w, hh, mat, ind, outd, full, alg, c, int(np.count_nonzero(got != want[c])))
+
+
+FIRF_SIZES = [(4, 2), (8, 4), (240, 8), (244, 6), (252, 130), (480, 264), (484, 12), (1000, 300), (1920, 540)]
+
+
+@pytest.mark.parametrize("w,hh", FIRF_SIZES)
+def test_fir_fused_kernel_geometries(oracle, w, hh):
+    """k_fir_fused (the FIR resampler in one pass: halo lanes, DPP taps, register history, integer FIR stages) vs the
+    oracle: widths of one lane, one strip, one strip + one lane, several strips with a partial last one; heights below
+    the filter's support, one segment, several segments (cuts recompute three row pairs either side); every matrix the
+    first tier covers, 8/10/12 bits, both ranges, both normalisation variants, half input, pictures with black bars
+    and out-of-table samples (every pixel of those takes the binary64 tier inside the loop)."""
+    import torch
+
+    rng = np.random.default_rng(w * 3 + hh)
+    fresh = h.Context(0)
+    fresh.set_option("fir", "fused")
+    try:
+        for (mat, depth, full, sample, stats) in ((h.MATRIX_BT2020NC, 12, 0, h.SAMPLE_F32, None), (h.MATRIX_BT709, 10, 1, h.SAMPLE_F32, [(0, 1)] * 3),
+                                                  (h.MATRIX_YDZDX, 12, 0, h.SAMPLE_F32, [(-1, 2)] * 3), (h.MATRIX_BT2020NC, 10, 0, h.SAMPLE_F16, [(0, 1)] * 3),
+                                                  (h.MATRIX_BT709, 8, 0, h.SAMPLE_F32, None)):
+            d = h.make_desc(w, hh, sample=sample, dst_depth=depth, dst_matrix=mat, resampler=1, full_range=full, stats=stats)
+            od = _to_oracle_desc(d)
+            n = 3
+            host = []
+            for k in range(n):
+                planes = _picture_like(rng, w, hh) if (k == 1 and w >= 48 and hh >= 16) else _rand_planes(rng, w, hh, h.SAMPLE_F32, plant=(w * hh >= 2))
+                if sample == h.SAMPLE_F16:
+                    planes = [np.asarray(p, np.float32).astype(np.float16).view(np.uint16) for p in planes]
+                host.append(planes)
+            conv = (lambda p: torch.from_numpy(np.ascontiguousarray(p).view(np.int16)).cuda()) if sample == h.SAMPLE_F16 else \
+                   (lambda p: torch.from_numpy(np.ascontiguousarray(p)).cuda())
+            dev_in = [[conv(p) for p in fr] for fr in host]
+            for rnd in range(2):  # round 0: statistics from a pre-pass (normalising variant); round 1: the hint (identity variant)
+                dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda") for _ in host]
+                torch.cuda.synchronize()
+                fresh.convert_batch(d, dev_in, dev_out)
+                assert fresh.last_kernel_name() == "k_fir_fused", fresh.last_kernel_variant()
+                for f in range(n):
+                    got = dev_out[f].cpu().numpy().view(np.uint16)
+                    want = oracle.convert_frame(od, host[f])
+                    bad = np.flatnonzero(got != want)
+                    assert bad.size == 0, f"{w}x{hh} mat {mat} depth {depth} round {rnd} frame {f}: {bad.size} samples differ, first at {bad[:8]} ({fresh.last_kernel_variant()})"
+    finally:
+        fresh.close()

@@ -14,3 +14,15 @@ def test_every_chunk_is_dealt_exactly_once(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert " 0 bad" in r.stdout
+
+
+def test_integer_fir_equals_float_fir(tmp_path):
+    """The fused FIR kernel runs Subsample444to420_FIR's two stages in integers (fir_h_int / fir_v_int, h2y_math.h)
+    for code values up to 14 bits; tools/fir_int_check.cpp compares them with the float forms (the restated
+    reference arithmetic) on random, extreme and flat inputs at every depth 8..14."""
+    exe = str(tmp_path / "fir_int_check")
+    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-std=c++17", "-I", os.path.join(ROOT, "hdr2yuv_amd", "csrc"),
+                    os.path.join(ROOT, "tools", "fir_int_check.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe, "300000"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert " 0 mismatches" in r.stdout

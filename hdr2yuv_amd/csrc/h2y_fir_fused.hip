@@ -12,8 +12,8 @@
  *   pixels -- 6 % -- so that no wave ever waits for another).
  *   Horizontal 7-tap (even columns): the taps at odd columns come from lanes L-2, L-1, L+1 by three DPP wave shifts
  *   of one packed dword per row and plane.
- *   Vertical 12-tap: each lane keeps the last eleven rows of ITS two 4:2:2 columns (both planes: 22 registers) and
- *   emits chroma row j = s - 3 at step s.  Picture edges replicate as the reference's index clamps do: rows above
+ *   Vertical 12-tap: each lane keeps the last eleven rows of ITS two 4:2:2 columns (both planes, two rows to a
+ *   register: 24 registers) and emits chroma row j = s - 3 at step s; the taps go two at a time (v_dot2_i32_i16).  Picture edges replicate as the reference's index clamps do: rows above
  *   the picture are row 0 (the history is filled with it at step 0), rows below are the last row (three virtual
  *   steps), the first and last column stand in for the columns beyond them.
  *   A frame's strip is cut into segments of rows so that a launch has enough waves' worth of work; a segment that
@@ -38,6 +38,9 @@
 #include "h2y_device.h"
 
 #define FF_THREADS 1024
+#ifndef FF_BUFFER_STORE
+#define FF_BUFFER_STORE 1 /* 1: chroma through range-checked buffer stores (lanes without a column are dropped by the hardware) */
+#endif
 #define FF_OWN_LANES 60 /* lanes 2 .. 61 own chroma: 240 picture columns per strip */
 
 struct ff_rows { /* one row pair of the lane's four columns, three planes */
@@ -45,19 +48,28 @@ struct ff_rows { /* one row pair of the lane's four columns, three planes */
 };
 
 /* lane L gets lane L-1's / L+1's value (DPP wave shifts; what arrives in lane 0 resp. 63 is never used) */
-__device__ __forceinline__ uint32_t from_lane_below(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, false); }
-__device__ __forceinline__ uint32_t from_lane_above(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130 /* wave_shl:1 */, 0xF, 0xF, false); }
+__device__ __forceinline__ uint32_t from_lane_below(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, true); }
+__device__ __forceinline__ uint32_t from_lane_above(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130 /* wave_shl:1 */, 0xF, 0xF, true); }
 
 struct ff_edges { /* per lane, fixed for a unit */
-    bool any;    /* the wave holds a picture edge (uniform) */
+    uint32_t any; /* the wave holds a picture edge (uniform, in a scalar register) */
     bool left0;  /* this lane's columns are the picture's first four */
     bool left1;  /* ... the next four */
     bool right0; /* ... the last four */
 };
 
-/* Horizontal stage for one row and plane (convert.cpp:291-320): c[0..3] = this lane's four 4:4:4 values; returns
- * the two 4:2:2 values at its even columns (column 4L | column 4L+2 << 16), clamped to [0, maxCV] and truncated. */
-__device__ __forceinline__ uint32_t ff_hstage(const uint32_t (&c)[4], const ff_edges &e, int32_t maxcv)
+/* two signed 16-bit products and a 32-bit sum in one instruction (v_dot2_i32_i16): the FIR taps in pairs */
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int32_t dot2(uint32_t v, uint32_t k, int32_t acc)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2, v), __builtin_bit_cast(s16x2, k), acc, false);
+}
+#define FF_K(lo, hi) (((uint32_t)(lo) & 0xFFFFu) | ((uint32_t)(hi) << 16))
+
+/* Horizontal stage for one row and plane (convert.cpp:291-320): c[0..3] = this lane's four 4:4:4 values (below
+ * 2^14); a, b = the 4:2:2 values at its even columns 4L and 4L+2, clamped to [0, maxCV] and truncated.  Integer
+ * form of fir_h() (h2y_math.h: exact up to 14 bits), the taps taken two at a time. */
+__device__ __forceinline__ void ff_hstage(const uint32_t (&c)[4], const ff_edges &e, int32_t maxcv, uint32_t &a, uint32_t &b)
 {
     const uint32_t p13 = c[1] | (c[3] << 16);
     uint32_t l1 = from_lane_below(p13); /* columns 4L-3, 4L-1 */
@@ -70,30 +82,49 @@ __device__ __forceinline__ uint32_t ff_hstage(const uint32_t (&c)[4], const ff_e
         l2 = e.left0 ? own0 : (e.left1 ? (c0_below << 16) : l2); /* 4L-5 = -1 -> column 0, which is the lane below's c[0] */
         r1 = e.right0 ? own3 : r1;
     }
-    const int32_t l1lo = (int32_t)(l1 & 0xFFFFu), l1hi = (int32_t)(l1 >> 16), l2hi = (int32_t)(l2 >> 16);
-    const int32_t r1lo = (int32_t)(r1 & 0xFFFFu), r1hi = (int32_t)(r1 >> 16);
-    const int32_t c0 = (int32_t)c[0], c1 = (int32_t)c[1], c2 = (int32_t)c[2], c3 = (int32_t)c[3];
-    /* even column i = 4L:   taps i-5 .. i+5 = (4L-5, 4L-3, 4L-1, 4L, 4L+1, 4L+3, 4L+5) */
-    const uint32_t a = fir_h_int(l2hi, l1lo, l1hi, c0, c1, c3, r1lo, maxcv);
-    /* even column i = 4L+2: (4L-3, 4L-1, 4L+1, 4L+2, 4L+3, 4L+5, 4L+7) */
-    const uint32_t b = fir_h_int(l1lo, l1hi, c1, c2, c3, r1lo, r1hi, maxcv);
-    return a | (b << 16);
+    /* even column i = 4L: 21 (s[i-5] + s[i+5]) - 52 (s[i-3] + s[i+3]) + 159 (s[i-1] + s[i+1]) + 256 s[i] + 256, all over 512 */
+    int32_t sa = (int32_t)((c[0] << 8) + 256u);
+    sa = dot2(l1, FF_K(-52, 159), sa);                               /* s[4L-3], s[4L-1] */
+    sa = dot2(p13, FF_K(159, -52), sa);                              /* s[4L+1], s[4L+3] */
+    sa = dot2(__builtin_amdgcn_alignbit(r1, l2, 16), FF_K(21, 21), sa); /* s[4L-5] (high half of l2), s[4L+5] (low half of r1) */
+    /* even column i = 4L+2 */
+    int32_t sb = (int32_t)((c[2] << 8) + 256u);
+    sb = dot2(l1, FF_K(21, -52), sb);   /* s[4L-3], s[4L-1] */
+    sb = dot2(p13, FF_K(159, 159), sb); /* s[4L+1], s[4L+3] */
+    sb = dot2(r1, FF_K(-52, 21), sb);   /* s[4L+5], s[4L+7] */
+    a = (uint32_t)imed3_0(sa >> 9, maxcv);
+    b = (uint32_t)imed3_0(sb >> 9, maxcv);
 }
 
-/* Vertical stage (convert.cpp:323-376) for both of the lane's 4:2:2 columns: h[0..10] = rows 2j-5 .. 2j+5, n0 = row
- * 2j+6; then write_yuv's chroma clamp (its range lies inside [0, maxCV], so one clamp does both). */
-__device__ __forceinline__ uint32_t ff_vstage(const uint32_t (&h)[11], uint32_t n0, int32_t clo, int32_t chi)
-{
-    uint32_t o[2];
+/* The lane's history of one 4:2:2 column and plane, rows two to a register: p[i] = row 2s-11+2i | row 2s-10+2i << 16
+ * (rows 2s-11 .. 2s-2), last = row 2s-1. */
+struct ff_hist {
+    uint32_t p[5], last;
+    __device__ __forceinline__ void fill(uint32_t v) /* every row is v (rows above the picture are row 0) */
+    {
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
-#define FFV(x) ((int32_t)(k ? (x) >> 16 : (x) & 0xFFFFu))
-        o[k] = fir_v_int(FFV(h[0]), FFV(h[1]), FFV(h[2]), FFV(h[3]), FFV(h[4]), FFV(h[5]), FFV(h[6]), FFV(h[7]), FFV(h[8]), FFV(h[9]), FFV(h[10]),
-                         FFV(n0), clo, chi);
-#undef FFV
+        for (int i = 0; i < 5; i++) p[i] = v | (v << 16);
+        last = v;
     }
-    return o[0] | (o[1] << 16);
-}
+    /* Vertical stage (convert.cpp:323-376) for chroma row j = s - 3 with n0 = row 2s: rows 2j-5 .. 2j+6 against
+     * (5 11 -21 -37 70 228 228 70 -37 -21 11 5)/512, then write_yuv's chroma clamp (inside [0, maxCV]: one clamp). */
+    __device__ __forceinline__ uint32_t out(uint32_t n0, int32_t clo, int32_t chi) const
+    {
+        int32_t sv = dot2(p[0], FF_K(5, 11), 256);
+        sv = dot2(p[1], FF_K(-21, -37), sv);
+        sv = dot2(p[2], FF_K(70, 228), sv);
+        sv = dot2(p[3], FF_K(228, 70), sv);
+        sv = dot2(p[4], FF_K(-37, -21), sv);
+        sv = dot2(last | (n0 << 16), FF_K(11, 5), sv);
+        return (uint32_t)imed3(sv >> 9, clo, chi);
+    }
+    __device__ __forceinline__ void push(uint32_t n0, uint32_t n1) /* on to step s + 1 */
+    {
+        p[0] = p[1]; p[1] = p[2]; p[2] = p[3]; p[3] = p[4];
+        p[4] = last | (n0 << 16);
+        last = n1;
+    }
+};
 
 template <int IN_KIND, int MODE, int PIPE>
 __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
@@ -122,16 +153,22 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
     /* a wave's units: u = gw, gw + GW, ...; unit = (frame, segment, strip), strips of one band next to each other
      * so that the sixteen waves of a block fill whole lines of the output between them */
     for (uint32_t u = gw; u < a.total_units; u += GW) {
-        const uint32_t f = u / a.units_per_frame, r = u - f * a.units_per_frame;
-        const uint32_t seg = r / a.n_strips, strip = r - seg * a.n_strips;
+        /* (uniform values; the divisions run on the vector unit, so say so) */
+        const uint32_t f = __builtin_amdgcn_readfirstlane(u / a.units_per_frame), r = u - f * a.units_per_frame;
+        const uint32_t seg = __builtin_amdgcn_readfirstlane(r / a.n_strips), strip = r - seg * a.n_strips;
         const frame_io io = uniform_io(a.frames + f);
-        const uint32_t j0 = seg * a.seg_rows, j1 = umin32(j0 + a.seg_rows, H2);   /* chroma rows [j0, j1) are this unit's */
+        const uint32_t j0 = seg * a.seg_rows, j1 = j0 + a.seg_rows < H2 ? j0 + a.seg_rows : H2;   /* chroma rows [j0, j1) are this unit's */
         const uint32_t s_begin = j0 >= 3u ? j0 - 3u : 0u, s_end = j1 + 2u;          /* steps: row pairs s_begin .. s_end (those >= H2 are virtual) */
         const int32_t qxu = (int32_t)(FF_OWN_LANES * strip + lane) - 2;             /* this lane's quad column, before clamping */
         const uint32_t qx = (uint32_t)min(max(qxu, 0), (int32_t)WQ - 1);
         const bool own = lane >= 2u && lane < 2u + FF_OWN_LANES && qxu < (int32_t)WQ;
+#if FF_BUFFER_STORE
+        const uint32_t qx_store = own ? qx : 0x20000000u; /* times four: past any frame, short of wrapping */
+        /* the frame's output as a raw buffer: stores beyond its last byte are dropped by the hardware's range check */
+        const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(io.out, 0, (int)((npix + 2u * ncb) * 2u), 0x00020000);
+#endif
         ff_edges e;
-        e.any = strip == 0u || strip + 1u == a.n_strips;
+        e.any = __builtin_amdgcn_readfirstlane((uint32_t)(strip == 0u) | (uint32_t)(strip + 1u == a.n_strips));
         e.left0 = qxu == 0;
         e.left1 = qxu == 1;
         e.right0 = qxu == (int32_t)WQ - 1;
@@ -140,20 +177,19 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
         mm.reset();
         uint32_t flagged = 0; /* pixels the first tier could not settle (uniform) */
         uint64_t low_m = 0;   /* lanes that met a sample <= -1 (see k_fused_t1: the minimum is only sampled) */
-        uint32_t hcb[11], hcr[11]; /* rows 2s-11 .. 2s-1 of the 4:2:2 intermediate, this lane's two columns */
-#pragma unroll
-        for (int k = 0; k < 11; k++) hcb[k] = hcr[k] = 0u;
+        ff_hist hb[2], hr[2]; /* rows 2s-11 .. 2s-1 of the 4:2:2 intermediate: Cb and Cr, this lane's columns 4L and 4L+2 */
+        hb[0].fill(0u); hb[1].fill(0u); hr[0].fill(0u); hr[1].fill(0u);
 
         ff_rows v; /* the row pair in hand; refilled row by row with the next one */
-        uint32_t q0 = 2u * umin32(s_begin, H2 - 1u) * WQ + qx;
+        uint32_t q0 = 2u * (s_begin < H2 - 1u ? s_begin : H2 - 1u) * WQ + qx; /* (scalar min: the loop's bounds stay in scalar registers) */
         IN::load4q(io.in[0], q0, v.g0); IN::load4q(io.in[1], q0, v.b0); IN::load4q(io.in[2], q0, v.r0);
         IN::load4q(io.in[0], q0 + WQ, v.g1); IN::load4q(io.in[1], q0 + WQ, v.b1); IN::load4q(io.in[2], q0 + WQ, v.r1);
 #pragma unroll
         for (int j = 0; j < 4; j++) asm volatile("" ::"v"(v.g0[j]), "v"(v.b0[j]), "v"(v.r0[j]), "v"(v.g1[j]), "v"(v.b1[j]), "v"(v.r1[j]));
 
         for (uint32_t s = s_begin; s <= s_end; s++) {
-            const uint32_t q0n = 2u * umin32(s + 1u, H2 - 1u) * WQ + qx; /* the next step's rows (the last rows again once the picture ends) */
-            uint32_t yp[2][2], n_cb[2], n_cr[2];
+            const uint32_t q0n = 2u * (s + 1u < H2 - 1u ? s + 1u : H2 - 1u) * WQ + qx; /* the next step's rows (the last rows again once the picture ends) */
+            uint32_t yp[2][2], n_cb[2][2], n_cr[2][2]; /* new 4:2:2 values: [row][column 4L / 4L+2] */
 #pragma unroll
             for (int row = 0; row < 2; row++) {
                 const float(&gv)[4] = row ? v.g1 : v.g0;
@@ -200,8 +236,8 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
                 }
                 yp[row][0] = pix_yuv_clamp<true>(pp, Y[0], false) | (pix_yuv_clamp<true>(pp, Y[1], false) << 16);
                 yp[row][1] = pix_yuv_clamp<true>(pp, Y[2], false) | (pix_yuv_clamp<true>(pp, Y[3], false) << 16);
-                n_cb[row] = ff_hstage(Cb, e, maxcv);
-                n_cr[row] = ff_hstage(Cr, e, maxcv);
+                ff_hstage(Cb, e, maxcv, n_cb[row][0], n_cb[row][1]);
+                ff_hstage(Cr, e, maxcv, n_cr[row][0], n_cr[row][1]);
                 if (row == 0) { /* row 0 of the next step, into the registers just read for the last time */
                     IN::load4q(io.in[0], q0n, v.g0);
                     IN::load4q(io.in[1], q0n, v.b0);
@@ -216,29 +252,40 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
             IN::load4q(io.in[2], q0n + WQ, v.r1);
 
             if (s >= H2) { /* below the picture: both new rows are its last row (convert.cpp:337-347) */
-                n_cb[0] = n_cb[1] = hcb[10];
-                n_cr[0] = n_cr[1] = hcr[10];
+#pragma unroll
+                for (int k = 0; k < 2; k++) {
+                    n_cb[0][k] = n_cb[1][k] = hb[k].last;
+                    n_cr[0][k] = n_cr[1][k] = hr[k].last;
+                }
             }
             if (s == 0u) { /* above the picture: row 0 (the same clamps) */
 #pragma unroll
-                for (int k = 0; k < 11; k++) { hcb[k] = n_cb[0]; hcr[k] = n_cr[0]; }
+                for (int k = 0; k < 2; k++) { hb[k].fill(n_cb[0][k]); hr[k].fill(n_cr[0][k]); }
             }
             /* chroma row j = s - 3 from rows 2j-5 .. 2j+6 = history + the new row 2s.  Before the history is whole
              * (j < j0) the value is not yet that row's: it goes to row j0, which this lane overwrites in order */
-            uint32_t ocb = ff_vstage(hcb, n_cb[0], clo, chi), ocr = ff_vstage(hcr, n_cr[0], clo, chi);
+            const uint32_t ocb = hb[0].out(n_cb[0][0], clo, chi) | (hb[1].out(n_cb[0][1], clo, chi) << 16);
+            const uint32_t ocr = hr[0].out(n_cr[0][0], clo, chi) | (hr[1].out(n_cr[0][1], clo, chi) << 16);
             const uint32_t jj = (s >= j0 + 3u) ? s - 3u : j0;
-            uint32_t cidx = jj * WQ + qx; /* dword index in a chroma plane: two samples per quad column */
+            /* dword index in a chroma plane: two samples per quad column.  Lanes that own no chroma column of this
+             * strip carry an index far beyond the frame: the buffer store drops them (no branch, no select) */
+#if FF_BUFFER_STORE
+            const uint32_t cidx = jj * WQ + qx_store;
+            __builtin_amdgcn_raw_buffer_store_b32(ocb, out_rsrc, (int)(((npix >> 1) + cidx) << 2), 0, 2 /* nt */);
+            __builtin_amdgcn_raw_buffer_store_b32(ocr, out_rsrc, (int)((((npix + ncb) >> 1) + cidx) << 2), 0, 2 /* nt */);
+#else
+            uint32_t cidx = jj * WQ + qx;
             /* lanes that own no chroma column of this strip store lane 2's dword once more */
             const uint32_t ocb2 = __builtin_amdgcn_readlane(ocb, 2), ocr2 = __builtin_amdgcn_readlane(ocr, 2), cidx2 = __builtin_amdgcn_readlane(cidx, 2);
-            ocb = own ? ocb : ocb2;
-            ocr = own ? ocr : ocr2;
             cidx = own ? cidx : cidx2;
-            gstore_nt<uint32_t>(io.out, (npix >> 1) + cidx, ocb);
-            gstore_nt<uint32_t>(io.out, ((npix + ncb) >> 1) + cidx, ocr);
+            gstore_nt<uint32_t>(io.out, (npix >> 1) + cidx, own ? ocb : ocb2);
+            gstore_nt<uint32_t>(io.out, ((npix + ncb) >> 1) + cidx, own ? ocr : ocr2);
+#endif
 #pragma unroll
-            for (int k = 0; k < 9; k++) { hcb[k] = hcb[k + 2]; hcr[k] = hcr[k + 2]; }
-            hcb[9] = n_cb[0]; hcb[10] = n_cb[1];
-            hcr[9] = n_cr[0]; hcr[10] = n_cr[1];
+            for (int k = 0; k < 2; k++) {
+                hb[k].push(n_cb[0][k], n_cb[1][k]);
+                hr[k].push(n_cr[0][k], n_cr[1][k]);
+            }
             q0 = q0n;
         }
         /* drain the loads the last step asked for (their registers are reused by the next unit's first loads) */

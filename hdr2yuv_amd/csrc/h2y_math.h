@@ -1038,11 +1038,22 @@ H2Y_FN uint32_t fir_v(float m5, float m4, float m3, float m2, float m1, float m0
 H2Y_FN int32_t imed3(int32_t v, int32_t lo, int32_t hi)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    int32_t r;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
+    int32_t r; /* one scalar operand per instruction on this family: lo from a scalar register, hi from a vector one */
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "s"(lo), "v"(hi));
     return r;
 #else
     return v < lo ? lo : (v > hi ? hi : v);
+#endif
+}
+/* clamp to [0, hi] (hi uniform) */
+H2Y_FN int32_t imed3_0(int32_t v, int32_t hi)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    int32_t r;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(r) : "v"(v), "s"(hi));
+    return r;
+#else
+    return v < 0 ? 0 : (v > hi ? hi : v);
 #endif
 }
 #define H2Y_FIR_INT_MAX_DEPTH 14

@@ -973,12 +973,15 @@ def test_fir_fused_kernel_geometries(oracle, w, hh):
     import torch
 
     rng = np.random.default_rng(w * 3 + hh)
-    fresh = h.Context(0)
-    fresh.set_option("fir", "fused")
+    fresh = None
     try:
         for (mat, depth, full, sample, stats) in ((h.MATRIX_BT2020NC, 12, 0, h.SAMPLE_F32, None), (h.MATRIX_BT709, 10, 1, h.SAMPLE_F32, [(0, 1)] * 3),
                                                   (h.MATRIX_YDZDX, 12, 0, h.SAMPLE_F32, [(-1, 2)] * 3), (h.MATRIX_BT2020NC, 10, 0, h.SAMPLE_F16, [(0, 1)] * 3),
                                                   (h.MATRIX_BT709, 8, 0, h.SAMPLE_F32, None)):
+            if fresh is not None:
+                fresh.close()
+            fresh = h.Context(0)  # tier steering starts from scratch: the first batch takes the first tier
+            fresh.set_option("fir", "fused")
             d = h.make_desc(w, hh, sample=sample, dst_depth=depth, dst_matrix=mat, resampler=1, full_range=full, stats=stats)
             od = _to_oracle_desc(d)
             n = 3
@@ -995,11 +998,13 @@ def test_fir_fused_kernel_geometries(oracle, w, hh):
                 dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda") for _ in host]
                 torch.cuda.synchronize()
                 fresh.convert_batch(d, dev_in, dev_out)
-                assert fresh.last_kernel_name() == "k_fir_fused", fresh.last_kernel_variant()
+                if rnd == 0:  # (a batch dense in out-of-table samples sends the NEXT ones to the binary64 two-pass form)
+                    assert fresh.last_kernel_name() == "k_fir_fused", fresh.last_kernel_variant()
                 for f in range(n):
                     got = dev_out[f].cpu().numpy().view(np.uint16)
                     want = oracle.convert_frame(od, host[f])
                     bad = np.flatnonzero(got != want)
                     assert bad.size == 0, f"{w}x{hh} mat {mat} depth {depth} round {rnd} frame {f}: {bad.size} samples differ, first at {bad[:8]} ({fresh.last_kernel_variant()})"
     finally:
-        fresh.close()
+        if fresh is not None:
+            fresh.close()

@@ -151,8 +151,15 @@ def run_steps(ctx, d, n_frames, ins, outs, steps, warmup, barrier):
     kms = 0.0
     redone = 0
     launches = 0
-    for _ in range(steps):
+    # two batches in flight: step k+1 is queued behind step k before step k's statistics are looked at, so the
+    # launches follow each other without a gap (same stream: the kernels never overlap, each one's HIP events are its own)
+    for k in range(steps):
         ctx.convert_batch_enqueue_raw(d, n_frames, ins, outs)
+        if k > 0:
+            redone += ctx.batch_finish()
+            ms, launches = ctx.last_kernel_ms()
+            kms += ms
+    if steps > 0:
         redone += ctx.batch_finish()
         ms, launches = ctx.last_kernel_ms()
         kms += ms

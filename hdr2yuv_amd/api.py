@@ -257,7 +257,7 @@ class Context:
 
     def convert_batch_enqueue(self, d: H2YDesc, frames_in, frames_out) -> None:
         n, ins, outs = self._batch_arrays(frames_in, frames_out)
-        self._keep = (ins, outs)
+        self._keep = (getattr(self, "_keep", ()) + ((ins, outs),))[-2:]  # up to two batches in flight
         self._check(self.lib.h2y_convert_batch_enqueue(self.h, C.byref(d), n, ins, outs))
 
     def convert_batch_enqueue_raw(self, d: H2YDesc, n: int, ins, outs) -> None:

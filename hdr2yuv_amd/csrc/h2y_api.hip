@@ -59,8 +59,46 @@ const int kFirSubBatch = 32; /* frames per fused launch on the FIR path: every l
 
 } // namespace
 
+/* Everything one batch in flight owns: two of them let h2y_convert_batch_enqueue() queue batch k+1 behind batch k
+ * before h2y_batch_finish() has looked at k (the 35 us between two launches -- the statistics kernel, one copy, the
+ * host's turn-around -- disappear behind the running kernel). */
+struct batch_state {
+    /* per-batch device arrays */
+    frame_io *d_frames = nullptr, *h_frames = nullptr;
+    size_t frames_cap = 0;
+    std::vector<frame_io> dev_frames; /* what d_frames holds (size frames_cap once anything was copied; cleared when d_frames is reallocated) */
+    float *d_partial = nullptr;
+    size_t partial_cap = 0;
+    uint32_t *d_redo = nullptr; /* k_fused_t1: per-wave counts of redone tiles */
+    size_t redo_cap = 0;
+    uint32_t *d_low = nullptr;  /* k_fused_t1: per-frame flag "a sample <= -1 was seen" (zero between launches) */
+    size_t low_cap = 0;
+    bool approx_min = false;    /* the batch's statistics hold a subsampled minimum (exact only where they match) */
+    unsigned long long *d_clock = nullptr;
+    size_t clock_cap = 0;
+    int bal_slot = 0;                         /* the eight run times travel in the frame_stats entry after the batch's last */
+    bool bal_pending = false;                 /* h_fstats[bal_slot] will hold the times of a launch dealt with bal_used_* */
+    uint32_t bal_used_mask = 0xFFu;
+    double bal_used_extra = 0.0;              /* work of a fast block relative to a slow one, minus one, in that launch */
+    frame_stats *d_fstats = nullptr, *h_fstats = nullptr;
+    assumed_stats *d_assumed = nullptr, *h_assumed = nullptr; /* [2]: [0] batch, [1] redo */
+    /* the batch itself, between enqueue and finish */
+    h2y_desc p_desc;
+    int p_n = 0;
+    bool p_check = false;
+    bool was_t1 = false;
+    std::vector<frame_io> p_frames;
+    hipEvent_t ev_done = nullptr; /* after the batch's last operation on the stream (the copy of its statistics) */
+    /* timing of the main kernels */
+    hipEvent_t ev[kMaxEvents][2];
+    int n_ev = 0;
+};
+
 struct h2y_ctx {
     int device = 0;
+    batch_state bs[2];
+    batch_state *b = &bs[0]; /* the batch the shim is working on (enqueue: the newest; finish: the oldest) */
+    int q_head = 0, q_count = 0; /* batches in flight: bs[q_head] is the oldest */
     int n_cu = 0;
     hipStream_t own_stream = nullptr, stream = nullptr;
     /* FIR pass runs on its own stream so that it overlaps the next sub-batch's fused kernel */
@@ -70,28 +108,12 @@ struct h2y_ctx {
     void *d_table = nullptr;
     void *d_table1 = nullptr; /* binary32 first-tier records */
     float *d_lut16 = nullptr; /* PQ10000_r of every half in [0,2), built on the device at creation */
-    /* per-batch device arrays */
-    frame_io *d_frames = nullptr, *h_frames = nullptr;
-    size_t frames_cap = 0;
-    std::vector<frame_io> dev_frames; /* what d_frames holds (size frames_cap once anything was copied; cleared when d_frames is reallocated) */
-    float *d_partial = nullptr;
-    uint32_t *d_redo = nullptr; /* k_fused_t1: per-wave counts of redone tiles */
-    uint32_t *d_low = nullptr;  /* k_fused_t1: per-frame flag "a sample <= -1 was seen" (zero between launches) */
-    size_t low_cap = 0;
-    bool approx_min = false;    /* the last batch's statistics hold a subsampled minimum (exact only where they match) */
-    size_t redo_cap = 0;
     /* The first tier is slow on pictures with many exactly-zero samples (black bars: every such tile is done twice).
      * The kernel counts the tiles it had to redo; when their share in a batch exceeds kT1DenseShare the next
      * kT1SkipBatches batches go to k_fused2 (the binary64 tier answers zero by itself), then the first tier is
      * tried again. */
     /* Balancing across XCDs (frame_walk in h2y_kernels.hip): the loop-form kernels leave the mean run time of the blocks
      * of each XCD; the shares of the next launch follow the speeds seen (balance_update()). */
-    unsigned long long *d_clock = nullptr;
-    size_t clock_cap = 0;
-    int bal_slot = 0;                         /* the eight run times travel in the frame_stats entry after the batch's last */
-    bool bal_pending = false;                 /* h_fstats[bal_slot] will hold the times of a launch dealt with bal_used_* */
-    uint32_t bal_used_mask = 0xFFu;
-    double bal_used_extra = 0.0;              /* work of a fast block relative to a slow one, minus one, in that launch */
     bool bal_have = false;
     double bal_speed[8] = {1, 1, 1, 1, 1, 1, 1, 1};
     uint32_t bal_mask = 0xFFu;                /* the XCDs that get the second part */
@@ -106,11 +128,6 @@ struct h2y_ctx {
     uint32_t opt_bal_mask = 0xFFu;
     double opt_bal_rho = 1.0;
     int opt_fir = 0;           /* "fir": 0 auto, 1 two-pass (4:4:4 scratch + k_fir420), 2 fused single pass where it applies */
-    bool last_was_t1 = false;
-    size_t partial_cap = 0;
-    frame_stats *d_fstats = nullptr, *h_fstats = nullptr;
-    size_t fstats_cap = 0;
-    assumed_stats *d_assumed = nullptr, *h_assumed = nullptr; /* [2]: [0] batch, [1] redo */
     uint16_t *d_tmp = nullptr;
     size_t tmp_cap = 0;
     uint16_t *d_up = nullptr; /* h2y_inverse_420(): the two upsampled chroma planes */
@@ -141,15 +158,6 @@ struct h2y_ctx {
     int s_head = 0, s_tail = 0, s_lent = -1;
     bool streaming = false;
     int slot_base = 0; /* run_frames(): first entry of d_frames/h_frames to use (one per stream slot) */
-    /* pending batch */
-    bool pending = false;
-    h2y_desc p_desc;
-    int p_n = 0;
-    bool p_check = false;
-    std::vector<frame_io> p_frames;
-    /* timing of the main kernels */
-    hipEvent_t ev[kMaxEvents][2];
-    int n_ev = 0;
     float last_ms = 0.f;
     const char *last_name = "";
     std::string last_variant; /* last_name with its template arguments and launch shape, e.g. "k_fused_t1<F32,420BOX,YCBCR,PQ_IDENT> groups=8 xcd=1" */
@@ -309,7 +317,7 @@ void t1_begin_batch(h2y_ctx *ctx)
 /* end of a batch that ran k_fused_t1: how many of its tiles had to be redone */
 void t1_end_batch(h2y_ctx *ctx, const h2y_desc *d, const frame_stats *fs, int n)
 {
-    if (!ctx->last_was_t1 || n < 1) return;
+    if (!ctx->b->was_t1 || n < 1) return;
     uint64_t redone = 0;
     for (int f = 0; f < n; f++) redone += fs[f].redone;
     const uint64_t tiles = (uint64_t)n * make_geom(d, 1024).tiles;
@@ -383,13 +391,13 @@ void balance_for_launch(const h2y_ctx *ctx, uint32_t cpf, uint32_t *mask, uint32
 /* after a launch whose block clocks came back: speeds per XCD, and from them the next launch's shares */
 void balance_update(h2y_ctx *ctx)
 {
-    if (!ctx->bal_pending) return;
-    ctx->bal_pending = false;
+    if (!ctx->b->bal_pending) return;
+    ctx->b->bal_pending = false;
     double sp[8], mean = 0.0;
     for (int x = 0; x < 8; x++) {
-        const double t = reinterpret_cast<const float *>(ctx->h_fstats + ctx->bal_slot)[x];
+        const double t = reinterpret_cast<const float *>(ctx->b->h_fstats + ctx->b->bal_slot)[x];
         if (!(t > 0.0)) return; /* grid smaller than a round of XCDs, or nothing measured */
-        const double w = ((ctx->bal_used_mask >> x) & 1u) && ctx->bal_used_mask != 0xFFu ? 1.0 + ctx->bal_used_extra : 1.0;
+        const double w = ((ctx->b->bal_used_mask >> x) & 1u) && ctx->b->bal_used_mask != 0xFFu ? 1.0 + ctx->b->bal_used_extra : 1.0;
         sp[x] = w / t;
         mean += sp[x] / 8.0;
     }
@@ -429,7 +437,7 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
     /* k_fused_t1's redo list numbers tiles as frame * tiles + tile in 32 bits */
     if ((var.pipe == 4 || var.pipe == 5) && (uint64_t)n * make_geom(d, h2y_fused_threads(var)).tiles >= 0xFFFFFFFFull) var.pipe -= 3;
     if ((var.pipe == 4 || var.pipe == 5) && ctx->cur_skip_t1) var.pipe -= 3; /* dense zeros lately: binary64 tier for now */
-    ctx->last_was_t1 = var.pipe == 4 || var.pipe == 5;
+    ctx->b->was_t1 = var.pipe == 4 || var.pipe == 5;
     if (var.pipe == 3 && d->width % 8 == 0) { /* half input through the table: 8-column tiles when every plane allows 16-byte accesses */
         bool ok = ctx->opt_cols8;
         for (int i = 0; i < n && ok; i++) {
@@ -454,33 +462,33 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         if (ctx->opt_fir == 2 || 2u * units >= gw) {
             const bool ident = var.pipe == 4 || var.pipe == 3; /* assumed floor 0 / ceiling 1 (pipe 3: half input, the table kernel's case) */
             const uint32_t upf = ns * nseg;
-            ctx->last_was_t1 = true;
-            bool on_device = ctx->dev_frames.size() == ctx->frames_cap;
-            if (!on_device) ctx->dev_frames.assign(ctx->frames_cap, frame_io{});
+            ctx->b->was_t1 = true;
+            bool on_device = ctx->b->dev_frames.size() == ctx->b->frames_cap;
+            if (!on_device) ctx->b->dev_frames.assign(ctx->b->frames_cap, frame_io{});
             for (int i = 0; i < n; i++) {
                 const size_t idx = (size_t)ctx->slot_base + i;
-                on_device = on_device && memcmp(&ctx->dev_frames[idx], &frames[i], sizeof(frame_io)) == 0;
-                ctx->h_frames[idx] = frames[i];
+                on_device = on_device && memcmp(&ctx->b->dev_frames[idx], &frames[i], sizeof(frame_io)) == 0;
+                ctx->b->h_frames[idx] = frames[i];
             }
             if (!on_device) {
-                HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frames + ctx->slot_base, ctx->h_frames + ctx->slot_base, n * sizeof(frame_io), hipMemcpyHostToDevice, ctx->stream));
-                for (int i = 0; i < n; i++) ctx->dev_frames[(size_t)ctx->slot_base + i] = ctx->h_frames[(size_t)ctx->slot_base + i];
+                HIP_TRY(ctx, hipMemcpyAsync(ctx->b->d_frames + ctx->slot_base, ctx->b->h_frames + ctx->slot_base, n * sizeof(frame_io), hipMemcpyHostToDevice, ctx->stream));
+                for (int i = 0; i < n; i++) ctx->b->dev_frames[(size_t)ctx->slot_base + i] = ctx->b->h_frames[(size_t)ctx->slot_base + i];
             }
-            int rc = ensure(ctx, ctx->d_partial, ctx->partial_cap, (size_t)n * upf * 6 * sizeof(float));
+            int rc = ensure(ctx, ctx->b->d_partial, ctx->b->partial_cap, (size_t)n * upf * 6 * sizeof(float));
             if (rc) return rc;
-            rc = ensure(ctx, ctx->d_redo, ctx->redo_cap, (size_t)n * upf * sizeof(uint32_t));
+            rc = ensure(ctx, ctx->b->d_redo, ctx->b->redo_cap, (size_t)n * upf * sizeof(uint32_t));
             if (rc) return rc;
             if (ident) {
                 const size_t need = (size_t)(n > 64 ? n : 64) * sizeof(uint32_t);
-                if (ctx->low_cap < need) {
-                    rc = ensure(ctx, ctx->d_low, ctx->low_cap, need);
+                if (ctx->b->low_cap < need) {
+                    rc = ensure(ctx, ctx->b->d_low, ctx->b->low_cap, need);
                     if (rc) return rc;
-                    HIP_TRY(ctx, hipMemsetAsync(ctx->d_low, 0, need, ctx->stream));
+                    HIP_TRY(ctx, hipMemsetAsync(ctx->b->d_low, 0, need, ctx->stream));
                 }
             }
-            if (check) ctx->approx_min = ident;
+            if (check) ctx->b->approx_min = ident;
             firf_args fa;
-            fa.frames = ctx->d_frames + ctx->slot_base;
+            fa.frames = ctx->b->d_frames + ctx->slot_base;
             fa.n_frames = n;
             fa.width = (uint32_t)d->width;
             fa.height = (uint32_t)d->height;
@@ -493,16 +501,16 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
             fa.table = ctx->d_table;
             fa.table1 = ctx->d_table1;
             fa.sn = sn;
-            fa.partial = ctx->d_partial;
-            fa.redo_count = ctx->d_redo;
-            fa.low_flag = ident ? ctx->d_low : nullptr;
+            fa.partial = ctx->b->d_partial;
+            fa.redo_count = ctx->b->d_redo;
+            fa.low_flag = ident ? ctx->b->d_low : nullptr;
             fa.assumed = d_assumed;
             fa.pp = pp;
             const uint32_t blocks_needed = (uint32_t)((units + 15u) / 16u);
             const int grid = (int)(blocks_needed < (uint32_t)ctx->n_cu ? blocks_needed : (uint32_t)ctx->n_cu);
-            const bool ev = time_it && ctx->n_ev < kMaxEvents;
+            const bool ev = time_it && ctx->b->n_ev < kMaxEvents;
             if (ev) {
-                HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->n_ev][0], ctx->stream));
+                HIP_TRY(ctx, hipEventRecord(ctx->b->ev[ctx->b->n_ev][0], ctx->stream));
                 ctx->last_name = "k_fir_fused";
                 char buf[192];
                 snprintf(buf, sizeof buf, "k_fir_fused<%s,420FIR,%s,%s> strips=%u segments=%u rows=%u", var.in_kind == H2Y_IN_F16 ? "F16" : "F32",
@@ -511,15 +519,15 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
             }
             HIP_TRY(ctx, h2y_launch_fir_fused(var.in_kind, var.mode, ident, grid, ctx->stream, fa));
             if (ev) {
-                HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->n_ev][1], ctx->stream));
-                ctx->n_ev++;
+                HIP_TRY(ctx, hipEventRecord(ctx->b->ev[ctx->b->n_ev][1], ctx->stream));
+                ctx->b->n_ev++;
             }
             final_args fin;
-            fin.partial = ctx->d_partial;
+            fin.partial = ctx->b->d_partial;
             fin.nblk = (int)upf;
-            fin.redo_count = ctx->d_redo;
-            fin.low_flag = ident ? ctx->d_low : nullptr;
-            fin.out = ctx->d_fstats + fstats_offset;
+            fin.redo_count = ctx->b->d_redo;
+            fin.low_flag = ident ? ctx->b->d_low : nullptr;
+            fin.out = ctx->b->d_fstats + fstats_offset;
             fin.is_u16 = 0;
             fin.src_bit_depth = d->src_bit_depth;
             fin.check = check ? 1 : 0;
@@ -550,8 +558,8 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_fir[half], 0));
         /* frame descriptors: host -> device (tiny) -- unless the device already holds exactly these (a caller
          * cycling through the same buffers): one stream operation less in front of the kernel */
-        bool on_device = ctx->dev_frames.size() == ctx->frames_cap;
-        if (!on_device) ctx->dev_frames.assign(ctx->frames_cap, frame_io{});
+        bool on_device = ctx->b->dev_frames.size() == ctx->b->frames_cap;
+        if (!on_device) ctx->b->dev_frames.assign(ctx->b->frames_cap, frame_io{});
         for (int i = 0; i < nf; i++) {
             frame_io io = frames[f0 + i];
             if (out_kind == H2Y_OUT_444TMP) {
@@ -559,13 +567,13 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
                 io.tmp_cr = io.tmp_cb + npix;
             }
             const size_t idx = (size_t)ctx->slot_base + f0 + i;
-            on_device = on_device && memcmp(&ctx->dev_frames[idx], &io, sizeof io) == 0;
-            ctx->h_frames[idx] = io;
+            on_device = on_device && memcmp(&ctx->b->dev_frames[idx], &io, sizeof io) == 0;
+            ctx->b->h_frames[idx] = io;
         }
         if (!on_device) {
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frames + ctx->slot_base + f0, ctx->h_frames + ctx->slot_base + f0, nf * sizeof(frame_io), hipMemcpyHostToDevice,
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->b->d_frames + ctx->slot_base + f0, ctx->b->h_frames + ctx->slot_base + f0, nf * sizeof(frame_io), hipMemcpyHostToDevice,
                                         ctx->stream));
-            for (int i = 0; i < nf; i++) ctx->dev_frames[(size_t)ctx->slot_base + f0 + i] = ctx->h_frames[(size_t)ctx->slot_base + f0 + i];
+            for (int i = 0; i < nf; i++) ctx->b->dev_frames[(size_t)ctx->slot_base + f0 + i] = ctx->b->h_frames[(size_t)ctx->slot_base + f0 + i];
         }
         const int grid = grid_for(ctx, var, (uint64_t)g.chunks * nf);
         const int waves = h2y_fused_threads(var) / 64; /* the fused kernels leave one min/max record per wave */
@@ -577,23 +585,23 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
                     groups = ng;
                     break;
                 }
-        int rc = ensure(ctx, ctx->d_partial, ctx->partial_cap, (size_t)nf * grid * waves * 6 * sizeof(float));
+        int rc = ensure(ctx, ctx->b->d_partial, ctx->b->partial_cap, (size_t)nf * grid * waves * 6 * sizeof(float));
         if (rc) return rc;
         const bool t1 = var.pipe == 4 || var.pipe == 5;
         if (t1) {
-            rc = ensure(ctx, ctx->d_redo, ctx->redo_cap, (size_t)nf * grid * waves * sizeof(uint32_t));
+            rc = ensure(ctx, ctx->b->d_redo, ctx->b->redo_cap, (size_t)nf * grid * waves * sizeof(uint32_t));
             if (rc) return rc;
         }
         const bool approx = var.pipe == 4; /* first tier, assumed floor 0 / ceiling 1: subsampled minimum */
         if (approx) {
             const size_t need = (size_t)(nf > 64 ? nf : 64) * sizeof(uint32_t);
-            if (ctx->low_cap < need) {
-                rc = ensure(ctx, ctx->d_low, ctx->low_cap, need);
+            if (ctx->b->low_cap < need) {
+                rc = ensure(ctx, ctx->b->d_low, ctx->b->low_cap, need);
                 if (rc) return rc;
-                HIP_TRY(ctx, hipMemsetAsync(ctx->d_low, 0, need, ctx->stream)); /* the kernels keep it zero from here on */
+                HIP_TRY(ctx, hipMemsetAsync(ctx->b->d_low, 0, need, ctx->stream)); /* the kernels keep it zero from here on */
             }
         }
-        if (check) ctx->approx_min = approx;
+        if (check) ctx->b->approx_min = approx;
         /* XCD-aware rounds and their weights; the block clocks of timed launches feed balance_update() */
         const bool xcd_layout = h2y_fused_grouped(var) && grid % (8 * groups) == 0;
         uint32_t fast_mask = 0xFFu, chunks_a = g.chunks;
@@ -602,20 +610,20 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         const bool clocks = xcd_layout && time_it;
         if (clocks) {
             const size_t need = (size_t)2 * grid * sizeof(unsigned long long);
-            if (ctx->clock_cap < need) {
-                rc = ensure(ctx, ctx->d_clock, ctx->clock_cap, need);
+            if (ctx->b->clock_cap < need) {
+                rc = ensure(ctx, ctx->b->d_clock, ctx->b->clock_cap, need);
                 if (rc) return rc;
-                HIP_TRY(ctx, hipMemsetAsync(ctx->d_clock, 0, need, ctx->stream)); /* k_stats_final clears the finish entries from here on */
+                HIP_TRY(ctx, hipMemsetAsync(ctx->b->d_clock, 0, need, ctx->stream)); /* k_stats_final clears the finish entries from here on */
             }
         }
         fused_args a;
         a.xcd_layout = xcd_layout ? 1u : 0u;
         a.fast_mask = fast_mask;
         a.chunks_a = chunks_a;
-        a.block_clock = clocks ? ctx->d_clock : nullptr;
-        a.redo_count = t1 ? ctx->d_redo : nullptr;
-        a.low_flag = approx ? ctx->d_low : nullptr;
-        a.frames = ctx->d_frames + ctx->slot_base + f0;
+        a.block_clock = clocks ? ctx->b->d_clock : nullptr;
+        a.redo_count = t1 ? ctx->b->d_redo : nullptr;
+        a.low_flag = approx ? ctx->b->d_low : nullptr;
+        a.frames = ctx->b->d_frames + ctx->slot_base + f0;
         a.n_frames = nf;
         a.width = d->width;
         a.height = d->height;
@@ -628,13 +636,13 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         a.lut16 = ctx->d_lut16;
         a.table1 = ctx->d_table1;
         a.sn = sn;
-        a.partial = ctx->d_partial;
+        a.partial = ctx->b->d_partial;
         a.assumed = d_assumed;
         a.pp = pp;
         a.tiles_magic = g.tiles > 1 ? (uint32_t)(0x100000000ull / g.tiles) : 0xFFFFFFFFu;
-        const bool ev = time_it && ctx->n_ev < kMaxEvents;
+        const bool ev = time_it && ctx->b->n_ev < kMaxEvents;
         if (ev) {
-            HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->n_ev][0], ctx->stream));
+            HIP_TRY(ctx, hipEventRecord(ctx->b->ev[ctx->b->n_ev][0], ctx->stream));
             ctx->last_name = h2y_fused_name(var);
             static const char *const kIn[] = {"F32", "F16", "U16"}, *const kOut[] = {"420BOX", "444", "444TMP"};
             static const char *const kPipe[] = {"RUNTIME", "PQ_IDENT", "PQ_NORM", "LUT16", "PQ_IDENT", "PQ_NORM", "NONE"};
@@ -646,36 +654,36 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         }
         HIP_TRY(ctx, h2y_launch_fused(var, grid, ctx->stream, a));
         if (ev) {
-            HIP_TRY(ctx, hipEventRecord(ctx->ev[ctx->n_ev][1], ctx->stream));
-            ctx->n_ev++;
+            HIP_TRY(ctx, hipEventRecord(ctx->b->ev[ctx->b->n_ev][1], ctx->stream));
+            ctx->b->n_ev++;
         }
         final_args fa;
-        fa.partial = ctx->d_partial;
+        fa.partial = ctx->b->d_partial;
         fa.nblk = grid / groups * waves;
-        fa.redo_count = t1 ? ctx->d_redo : nullptr;
-        fa.low_flag = approx ? ctx->d_low : nullptr;
-        fa.out = ctx->d_fstats + fstats_offset + f0;
+        fa.redo_count = t1 ? ctx->b->d_redo : nullptr;
+        fa.low_flag = approx ? ctx->b->d_low : nullptr;
+        fa.out = ctx->b->d_fstats + fstats_offset + f0;
         fa.is_u16 = d->in_sample_type == H2Y_SAMPLE_U16;
         fa.src_bit_depth = d->src_bit_depth;
         fa.check = check ? 1 : 0;
         fa.assumed = d_assumed;
         fa.publish = nullptr;
-        fa.block_clock = clocks ? ctx->d_clock : nullptr;
+        fa.block_clock = clocks ? ctx->b->d_clock : nullptr;
         fa.grid = grid;
         static_assert(sizeof(frame_stats) >= 8 * sizeof(float), "the XCD run times ride in one frame_stats entry");
-        fa.xcd_time = reinterpret_cast<float *>(ctx->d_fstats + fstats_offset + n); /* the caller's copy of the statistics takes one entry more */
+        fa.xcd_time = reinterpret_cast<float *>(ctx->b->d_fstats + fstats_offset + n); /* the caller's copy of the statistics takes one entry more */
         HIP_TRY(ctx, h2y_launch_stats_final(nf, ctx->stream, fa));
         if (clocks) {
-            ctx->bal_slot = fstats_offset + n;
-            ctx->bal_pending = true;
-            ctx->bal_used_mask = fast_mask;
-            ctx->bal_used_extra = extra;
+            ctx->b->bal_slot = fstats_offset + n;
+            ctx->b->bal_pending = true;
+            ctx->b->bal_used_mask = fast_mask;
+            ctx->b->bal_used_extra = extra;
         }
         if (out_kind == H2Y_OUT_444TMP) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev_fused[half], ctx->stream));
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->fir_stream, ctx->ev_fused[half], 0));
             fir_args fr;
-            fr.frames = ctx->d_frames + ctx->slot_base + f0;
+            fr.frames = ctx->b->d_frames + ctx->slot_base + f0;
             fr.n_frames = nf;
             fr.src_cb = fr.src_cr = nullptr;
             fr.dst_cb = fr.dst_cr = nullptr;
@@ -697,21 +705,21 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
 
 int reserve_batch(h2y_ctx *ctx, int n)
 {
-    if ((size_t)n > ctx->frames_cap) {
-        if (ctx->d_frames) HIP_TRY(ctx, hipFree(ctx->d_frames));
-        if (ctx->h_frames) HIP_TRY(ctx, hipHostFree(ctx->h_frames));
-        if (ctx->d_fstats) HIP_TRY(ctx, hipFree(ctx->d_fstats));
-        if (ctx->h_fstats) HIP_TRY(ctx, hipHostFree(ctx->h_fstats));
-        ctx->d_frames = nullptr; ctx->h_frames = nullptr; ctx->d_fstats = nullptr; ctx->h_fstats = nullptr;
-        ctx->frames_cap = 0;
-        ctx->dev_frames.clear();
+    if ((size_t)n > ctx->b->frames_cap) {
+        if (ctx->b->d_frames) HIP_TRY(ctx, hipFree(ctx->b->d_frames));
+        if (ctx->b->h_frames) HIP_TRY(ctx, hipHostFree(ctx->b->h_frames));
+        if (ctx->b->d_fstats) HIP_TRY(ctx, hipFree(ctx->b->d_fstats));
+        if (ctx->b->h_fstats) HIP_TRY(ctx, hipHostFree(ctx->b->h_fstats));
+        ctx->b->d_frames = nullptr; ctx->b->h_frames = nullptr; ctx->b->d_fstats = nullptr; ctx->b->h_fstats = nullptr;
+        ctx->b->frames_cap = 0;
+        ctx->b->dev_frames.clear();
         size_t cap = (size_t)n < 64 ? 64 : (size_t)n;
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_frames, cap * sizeof(frame_io)));
-        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_frames, cap * sizeof(frame_io), hipHostMallocDefault));
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->b->d_frames, cap * sizeof(frame_io)));
+        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->b->h_frames, cap * sizeof(frame_io), hipHostMallocDefault));
         /* +1: slot for the stats pre-pass / redo */
-        HIP_TRY(ctx, hipMalloc((void **)&ctx->d_fstats, (cap + 1) * sizeof(frame_stats)));
-        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_fstats, (cap + 1) * sizeof(frame_stats), hipHostMallocDefault));
-        ctx->frames_cap = cap;
+        HIP_TRY(ctx, hipMalloc((void **)&ctx->b->d_fstats, (cap + 1) * sizeof(frame_stats)));
+        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->b->h_fstats, (cap + 1) * sizeof(frame_stats), hipHostMallocDefault));
+        ctx->b->frames_cap = cap;
     }
     return 0;
 }
@@ -724,7 +732,7 @@ int run_stats(h2y_ctx *ctx, const h2y_desc *d, const void *const in[3], int slot
     int grid = ctx->n_cu * 4;
     size_t need_blocks = (npix / 4 + H2Y_FUSED_THREADS - 1) / H2Y_FUSED_THREADS;
     if ((size_t)grid > need_blocks) grid = need_blocks ? (int)need_blocks : 1;
-    int rc = ensure(ctx, ctx->d_partial, ctx->partial_cap, (size_t)grid * 6 * sizeof(float));
+    int rc = ensure(ctx, ctx->b->d_partial, ctx->b->partial_cap, (size_t)grid * 6 * sizeof(float));
     if (rc) return rc;
     stats_args sa;
     bool aligned = true;
@@ -734,12 +742,12 @@ int run_stats(h2y_ctx *ctx, const h2y_desc *d, const void *const in[3], int slot
     }
     sa.npix = npix;
     sa.vec_ok = aligned ? 1 : 0;
-    sa.partial = ctx->d_partial;
+    sa.partial = ctx->b->d_partial;
     HIP_TRY(ctx, h2y_launch_stats(in_kind_of(d), grid, ctx->stream, sa));
     final_args fa;
-    fa.partial = ctx->d_partial;
+    fa.partial = ctx->b->d_partial;
     fa.nblk = grid;
-    fa.out = ctx->d_fstats + slot;
+    fa.out = ctx->b->d_fstats + slot;
     fa.is_u16 = d->in_sample_type == H2Y_SAMPLE_U16;
     fa.src_bit_depth = d->src_bit_depth;
     fa.redo_count = nullptr;
@@ -824,7 +832,8 @@ const char *h2y_last_error(const h2y_ctx *ctx) { return ctx ? ctx->err.c_str() :
 static int ctx_init(h2y_ctx *ctx, int device)
 {
     ctx->device = device;
-    for (int i = 0; i < kMaxEvents; i++) ctx->ev[i][0] = ctx->ev[i][1] = nullptr;
+    for (batch_state &b : ctx->bs)
+        for (int i = 0; i < kMaxEvents; i++) b.ev[i][0] = b.ev[i][1] = nullptr;
     HIP_TRY(ctx, hipSetDevice(device));
     hipDeviceProp_t prop;
     HIP_TRY(ctx, hipGetDeviceProperties(&prop, device));
@@ -836,9 +845,12 @@ static int ctx_init(h2y_ctx *ctx, int device)
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fused[i], hipEventDisableTiming));
         HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->ev_fir[i], hipEventDisableTiming));
     }
-    for (int i = 0; i < kMaxEvents; i++) {
-        HIP_TRY(ctx, hipEventCreate(&ctx->ev[i][0]));
-        HIP_TRY(ctx, hipEventCreate(&ctx->ev[i][1]));
+    for (batch_state &b : ctx->bs) {
+        for (int i = 0; i < kMaxEvents; i++) {
+            HIP_TRY(ctx, hipEventCreate(&b.ev[i][0]));
+            HIP_TRY(ctx, hipEventCreate(&b.ev[i][1]));
+        }
+        HIP_TRY(ctx, hipEventCreateWithFlags(&b.ev_done, hipEventDisableTiming));
     }
     /* PQ fast-tier table: built on the host once, lives in HBM, staged to LDS per block */
     {
@@ -857,9 +869,15 @@ static int ctx_init(h2y_ctx *ctx, int device)
         HIP_TRY(ctx, h2y_launch_build_lut16(ctx->stream, ctx->d_table, ctx->d_lut16));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
-    HIP_TRY(ctx, hipMalloc((void **)&ctx->d_assumed, 2 * sizeof(assumed_stats)));
-    HIP_TRY(ctx, hipHostMalloc((void **)&ctx->h_assumed, 2 * sizeof(assumed_stats), hipHostMallocDefault));
-    return reserve_batch(ctx, 64);
+    for (batch_state &b : ctx->bs) {
+        HIP_TRY(ctx, hipMalloc((void **)&b.d_assumed, 2 * sizeof(assumed_stats)));
+        HIP_TRY(ctx, hipHostMalloc((void **)&b.h_assumed, 2 * sizeof(assumed_stats), hipHostMallocDefault));
+        ctx->b = &b;
+        const int rc = reserve_batch(ctx, 64);
+        if (rc) return rc;
+    }
+    ctx->b = &ctx->bs[0];
+    return H2Y_OK;
 }
 
 int h2y_ctx_create(int device, h2y_ctx **out)
@@ -892,7 +910,7 @@ int h2y_ctx_set_option(h2y_ctx *ctx, const char *name, const char *value)
 {
     if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
     if (!name || !value) return fail(ctx, H2Y_EINVAL, "null option name or value");
-    if (ctx->pending || ctx->streaming) return fail(ctx, H2Y_EINVAL, "a batch is pending or a stream is open");
+    if ((ctx->q_count > 0) || ctx->streaming) return fail(ctx, H2Y_EINVAL, "a batch is pending or a stream is open");
     if (!strcmp(name, "t1")) ctx->opt_t1 = value[0] != '0';
     else if (!strcmp(name, "cols8")) ctx->opt_cols8 = value[0] != '0';
     else if (!strcmp(name, "groups")) {
@@ -927,23 +945,26 @@ void h2y_ctx_destroy(h2y_ctx *ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     if (ctx->streaming) (void)h2y_stream_close(ctx);
-    for (int i = 0; i < kMaxEvents; i++) {
-        if (ctx->ev[i][0]) (void)hipEventDestroy(ctx->ev[i][0]);
-        if (ctx->ev[i][1]) (void)hipEventDestroy(ctx->ev[i][1]);
+    for (batch_state &b : ctx->bs) {
+        for (int i = 0; i < kMaxEvents; i++) {
+            if (b.ev[i][0]) (void)hipEventDestroy(b.ev[i][0]);
+            if (b.ev[i][1]) (void)hipEventDestroy(b.ev[i][1]);
+        }
+        if (b.ev_done) (void)hipEventDestroy(b.ev_done);
+        (void)hipFree(b.d_frames);
+        (void)hipHostFree(b.h_frames);
+        (void)hipFree(b.d_partial);
+        (void)hipFree(b.d_redo);
+        (void)hipFree(b.d_low);
+        (void)hipFree(b.d_clock);
+        (void)hipFree(b.d_fstats);
+        (void)hipHostFree(b.h_fstats);
+        (void)hipFree(b.d_assumed);
+        (void)hipHostFree(b.h_assumed);
     }
     (void)hipFree(ctx->d_table);
     (void)hipFree(ctx->d_lut16);
     (void)hipFree(ctx->d_table1);
-    (void)hipFree(ctx->d_frames);
-    (void)hipHostFree(ctx->h_frames);
-    (void)hipFree(ctx->d_partial);
-    (void)hipFree(ctx->d_redo);
-    (void)hipFree(ctx->d_low);
-    (void)hipFree(ctx->d_clock);
-    (void)hipFree(ctx->d_fstats);
-    (void)hipHostFree(ctx->h_fstats);
-    (void)hipFree(ctx->d_assumed);
-    (void)hipHostFree(ctx->h_assumed);
     (void)hipFree(ctx->d_tmp);
     (void)hipFree(ctx->d_up);
     (void)hipFree(ctx->d_in);
@@ -963,7 +984,7 @@ void h2y_ctx_destroy(h2y_ctx *ctx)
 int h2y_ctx_set_stream(h2y_ctx *ctx, void *hip_stream)
 {
     if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
-    if (ctx->pending) return fail(ctx, H2Y_EINVAL, "a batch is pending: call h2y_batch_finish first");
+    if ((ctx->q_count > 0)) return fail(ctx, H2Y_EINVAL, "a batch is pending: call h2y_batch_finish first");
     if (ctx->streaming) return fail(ctx, H2Y_EINVAL, "a stream is open: close it first");
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
     return H2Y_OK;
@@ -972,16 +993,17 @@ int h2y_ctx_set_stream(h2y_ctx *ctx, void *hip_stream)
 int h2y_convert_batch_enqueue(h2y_ctx *ctx, const h2y_desc *d, int n_frames, const void *const *d_in, uint16_t *const *d_out)
 {
     if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
-    if (ctx->pending) return fail(ctx, H2Y_EINVAL, "a batch is already pending: call h2y_batch_finish first");
+    if (ctx->q_count >= 2) return fail(ctx, H2Y_EINVAL, "two batches are already in flight: call h2y_batch_finish first");
     if (ctx->streaming) return fail(ctx, H2Y_EINVAL, "a stream is open: close it first");
     const char *why;
     int rc = h2y_desc_check(d, &why);
     if (rc) return fail(ctx, rc, "descriptor: %s", why);
     if (n_frames < 1 || !d_in || !d_out) return fail(ctx, H2Y_EINVAL, "n_frames < 1 or null pointer arrays");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->b = &ctx->bs[(ctx->q_head + ctx->q_count) & 1]; /* the free slot: its last batch was finished */
     rc = reserve_batch(ctx, n_frames);
     if (rc) return rc;
-    ctx->p_frames.resize(n_frames);
+    ctx->b->p_frames.resize(n_frames);
     for (int f = 0; f < n_frames; f++) {
         frame_io io;
         for (int c = 0; c < 3; c++) {
@@ -991,42 +1013,43 @@ int h2y_convert_batch_enqueue(h2y_ctx *ctx, const h2y_desc *d, int n_frames, con
         io.out = d_out[f];
         if (!io.out || ((uintptr_t)io.out & 15)) return fail(ctx, H2Y_EINVAL, "output of frame %d is null or not 16-byte aligned", f);
         io.tmp_cb = io.tmp_cr = nullptr;
-        ctx->p_frames[f] = io;
+        ctx->b->p_frames[f] = io;
     }
-    ctx->n_ev = 0;
+    ctx->b->n_ev = 0;
     const bool needs_stats = d->src_transfer != d->dst_transfer; /* convert.cpp:930-940: stats are only read then */
     bool check = false;
     bool host_knows = true;
-    assumed_stats *as = ctx->h_assumed;
+    assumed_stats *as = ctx->b->h_assumed;
     if (!needs_stats || d->stats_override) {
         for (int c = 0; c < 3; c++) {
             as->floor_[c] = d->stats_override ? d->floor[c] : 0;
             as->ceil_[c] = d->stats_override ? d->ceiling[c] : 1;
         }
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_assumed, as, sizeof *as, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->b->d_assumed, as, sizeof *as, hipMemcpyHostToDevice, ctx->stream));
     } else if (ctx->have_hint && ctx->hint_kind == d->in_sample_type) {
         /* assume this batch looks like the last frame we saw; verified below */
         for (int c = 0; c < 3; c++) {
             as->floor_[c] = ctx->hint_floor[c];
             as->ceil_[c] = ctx->hint_ceil[c];
         }
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_assumed, as, sizeof *as, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->b->d_assumed, as, sizeof *as, hipMemcpyHostToDevice, ctx->stream));
         check = true;
     } else {
         /* no history: measure frame 0 (pic_stats pre-pass) and assume the rest match it */
-        rc = run_stats(ctx, d, ctx->p_frames[0].in, (int)ctx->frames_cap, ctx->d_assumed);
+        rc = run_stats(ctx, d, ctx->b->p_frames[0].in, (int)ctx->b->frames_cap, ctx->b->d_assumed);
         if (rc) return rc;
         check = true;
         host_knows = false; /* the values exist only in device memory */
     }
     t1_begin_batch(ctx);
-    rc = run_frames(ctx, d, ctx->p_frames.data(), n_frames, ctx->d_assumed, host_knows ? ctx->h_assumed : nullptr, check, 0, true);
+    rc = run_frames(ctx, d, ctx->b->p_frames.data(), n_frames, ctx->b->d_assumed, host_knows ? ctx->b->h_assumed : nullptr, check, 0, true);
     if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_fstats, ctx->d_fstats, ((size_t)n_frames + 1) * sizeof(frame_stats), hipMemcpyDeviceToHost, ctx->stream)); /* + the XCD run times */
-    ctx->pending = true;
-    ctx->p_desc = *d;
-    ctx->p_n = n_frames;
-    ctx->p_check = check;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->b->h_fstats, ctx->b->d_fstats, ((size_t)n_frames + 1) * sizeof(frame_stats), hipMemcpyDeviceToHost, ctx->stream)); /* + the XCD run times */
+    HIP_TRY(ctx, hipEventRecord(ctx->b->ev_done, ctx->stream));
+    ctx->b->p_desc = *d;
+    ctx->b->p_n = n_frames;
+    ctx->b->p_check = check;
+    ctx->q_count++;
     return H2Y_OK;
 }
 
@@ -1034,37 +1057,39 @@ int h2y_batch_finish(h2y_ctx *ctx, int *n_redone)
 {
     if (n_redone) *n_redone = 0;
     if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
-    if (!ctx->pending) return H2Y_OK;
+    if (ctx->q_count == 0) return H2Y_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->pending = false;
+    ctx->b = &ctx->bs[ctx->q_head]; /* the oldest batch in flight; a younger one may still be running behind it */
+    ctx->q_head ^= 1;
+    ctx->q_count--;
+    HIP_TRY(ctx, hipEventSynchronize(ctx->b->ev_done));
     float ms = 0.f;
-    for (int i = 0; i < ctx->n_ev; i++) {
+    for (int i = 0; i < ctx->b->n_ev; i++) {
         float t = 0.f;
-        HIP_TRY(ctx, hipEventElapsedTime(&t, ctx->ev[i][0], ctx->ev[i][1]));
+        HIP_TRY(ctx, hipEventElapsedTime(&t, ctx->b->ev[i][0], ctx->b->ev[i][1]));
         ms += t;
     }
     ctx->last_ms = ms;
-    ctx->last_launches = ctx->n_ev;
+    ctx->last_launches = ctx->b->n_ev;
 #ifdef H2Y_BLOCK_TIMES
     if (const char *e = getenv("H2Y_BLOCK_TIMES_FILE")) h2y_dump_block_times(e);
 #endif
     int redone = 0;
-    const h2y_desc *d = &ctx->p_desc;
-    t1_end_batch(ctx, d, ctx->h_fstats, ctx->p_n);
+    const h2y_desc *d = &ctx->b->p_desc;
+    t1_end_batch(ctx, d, ctx->b->h_fstats, ctx->b->p_n);
     balance_update(ctx);
-    if (ctx->p_check) {
-        for (int f = 0; f < ctx->p_n; f++) {
-            if (!ctx->h_fstats[f].mismatch) continue;
-            if (ctx->approx_min) {
+    if (ctx->b->p_check) {
+        for (int f = 0; f < ctx->b->p_n; f++) {
+            if (!ctx->b->h_fstats[f].mismatch) continue;
+            if (ctx->b->approx_min) {
                 /* the kernel kept only a subsample of the minimum: what it measured is exact where it matched the
                  * assumption, not here -- take pic_stats() of this frame first, then the pixels, as
                  * h2y_convert_frame() does */
-                int rc = run_stats(ctx, d, ctx->p_frames[f].in, (int)ctx->frames_cap, ctx->d_assumed + 1);
+                int rc = run_stats(ctx, d, ctx->b->p_frames[f].in, (int)ctx->b->frames_cap, ctx->b->d_assumed + 1);
                 if (rc) return rc;
-                HIP_TRY(ctx, hipMemcpyAsync(ctx->h_fstats + f, ctx->d_fstats + ctx->frames_cap, sizeof(frame_stats), hipMemcpyDeviceToHost, ctx->stream));
+                HIP_TRY(ctx, hipMemcpyAsync(ctx->b->h_fstats + f, ctx->b->d_fstats + ctx->b->frames_cap, sizeof(frame_stats), hipMemcpyDeviceToHost, ctx->stream));
                 HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); /* before run_frames() reuses the slot */
-                rc = run_frames(ctx, d, &ctx->p_frames[f], 1, ctx->d_assumed + 1, nullptr, false, (int)ctx->frames_cap, false);
+                rc = run_frames(ctx, d, &ctx->b->p_frames[f], 1, ctx->b->d_assumed + 1, nullptr, false, (int)ctx->b->frames_cap, false);
                 if (rc) return rc;
                 HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
                 redone++;
@@ -1072,20 +1097,20 @@ int h2y_batch_finish(h2y_ctx *ctx, int *n_redone)
             }
             /* the assumption was wrong for this frame: its true floor/ceiling are now
              * known (the fused kernel measured them), so run it again with those */
-            assumed_stats *as = ctx->h_assumed + 1;
+            assumed_stats *as = ctx->b->h_assumed + 1;
             for (int c = 0; c < 3; c++) {
-                as->floor_[c] = ctx->h_fstats[f].floor_[c];
-                as->ceil_[c] = ctx->h_fstats[f].ceil_[c];
+                as->floor_[c] = ctx->b->h_fstats[f].floor_[c];
+                as->ceil_[c] = ctx->b->h_fstats[f].ceil_[c];
             }
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->d_assumed + 1, as, sizeof *as, hipMemcpyHostToDevice, ctx->stream));
-            int rc = run_frames(ctx, d, &ctx->p_frames[f], 1, ctx->d_assumed + 1, as, false, (int)ctx->frames_cap, false);
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->b->d_assumed + 1, as, sizeof *as, hipMemcpyHostToDevice, ctx->stream));
+            int rc = run_frames(ctx, d, &ctx->b->p_frames[f], 1, ctx->b->d_assumed + 1, as, false, (int)ctx->b->frames_cap, false);
             if (rc) return rc;
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
             redone++;
         }
     }
     if (d->src_transfer != d->dst_transfer && !d->stats_override) {
-        const frame_stats &last = ctx->h_fstats[ctx->p_n - 1];
+        const frame_stats &last = ctx->b->h_fstats[ctx->b->p_n - 1];
         for (int c = 0; c < 3; c++) {
             ctx->hint_floor[c] = last.floor_[c];
             ctx->hint_ceil[c] = last.ceil_[c];
@@ -1101,13 +1126,17 @@ int h2y_convert_batch(h2y_ctx *ctx, const h2y_desc *d, int n_frames, const void 
 {
     int rc = h2y_convert_batch_enqueue(ctx, d, n_frames, d_in, d_out);
     if (rc) return rc;
-    return h2y_batch_finish(ctx, nullptr);
+    while (ctx->q_count > 0) { /* this batch and any enqueued before it */
+        rc = h2y_batch_finish(ctx, nullptr);
+        if (rc) return rc;
+    }
+    return H2Y_OK;
 }
 
 int h2y_convert_frame(h2y_ctx *ctx, const h2y_desc *d, const void *const in_planes[3], uint16_t *out_yuv)
 {
     if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
-    if (ctx->pending) return fail(ctx, H2Y_EINVAL, "a batch is pending: call h2y_batch_finish first");
+    if ((ctx->q_count > 0)) return fail(ctx, H2Y_EINVAL, "a batch is pending: call h2y_batch_finish first");
     if (ctx->streaming) return fail(ctx, H2Y_EINVAL, "a stream is open: close it first");
     const char *why;
     int rc = h2y_desc_check(d, &why);
@@ -1130,34 +1159,34 @@ int h2y_convert_frame(h2y_ctx *ctx, const h2y_desc *d, const void *const in_plan
     const bool needs_stats = d->src_transfer != d->dst_transfer;
     bool host_knows = true;
     if (needs_stats && !d->stats_override) {
-        rc = run_stats(ctx, d, io.in, (int)ctx->frames_cap, ctx->d_assumed);
+        rc = run_stats(ctx, d, io.in, (int)ctx->b->frames_cap, ctx->b->d_assumed);
         if (rc) return rc;
         host_knows = false;
     } else {
-        assumed_stats *as = ctx->h_assumed;
+        assumed_stats *as = ctx->b->h_assumed;
         for (int c = 0; c < 3; c++) {
             as->floor_[c] = d->stats_override ? d->floor[c] : 0;
             as->ceil_[c] = d->stats_override ? d->ceiling[c] : 1;
         }
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_assumed, as, sizeof *as, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->b->d_assumed, as, sizeof *as, hipMemcpyHostToDevice, ctx->stream));
     }
-    ctx->n_ev = 0;
+    ctx->b->n_ev = 0;
     t1_begin_batch(ctx);
-    rc = run_frames(ctx, d, &io, 1, ctx->d_assumed, host_knows ? ctx->h_assumed : nullptr, false, 0, true);
+    rc = run_frames(ctx, d, &io, 1, ctx->b->d_assumed, host_knows ? ctx->b->h_assumed : nullptr, false, 0, true);
     if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->h_fstats, ctx->d_fstats, 2 * sizeof(frame_stats), hipMemcpyDeviceToHost, ctx->stream)); /* + the XCD run times */
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->b->h_fstats, ctx->b->d_fstats, 2 * sizeof(frame_stats), hipMemcpyDeviceToHost, ctx->stream)); /* + the XCD run times */
     HIP_TRY(ctx, hipMemcpyAsync(out_yuv, ctx->d_out, ob, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    t1_end_batch(ctx, d, ctx->h_fstats, 1);
+    t1_end_batch(ctx, d, ctx->b->h_fstats, 1);
     balance_update(ctx);
     float ms = 0.f;
-    for (int i = 0; i < ctx->n_ev; i++) {
+    for (int i = 0; i < ctx->b->n_ev; i++) {
         float t = 0.f;
-        HIP_TRY(ctx, hipEventElapsedTime(&t, ctx->ev[i][0], ctx->ev[i][1]));
+        HIP_TRY(ctx, hipEventElapsedTime(&t, ctx->b->ev[i][0], ctx->b->ev[i][1]));
         ms += t;
     }
     ctx->last_ms = ms;
-    ctx->last_launches = ctx->n_ev;
+    ctx->last_launches = ctx->b->n_ev;
     return H2Y_OK;
 }
 
@@ -1165,7 +1194,7 @@ int h2y_matrix_inverse(h2y_ctx *ctx, int width, int height, int in_bit_depth, in
                        int out_bit_depth, const uint16_t *const d_in[3], uint16_t *const d_out[3])
 {
     if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
-    if (ctx->pending || ctx->streaming) return fail(ctx, H2Y_EINVAL, "a batch is pending or a stream is open");
+    if ((ctx->q_count > 0) || ctx->streaming) return fail(ctx, H2Y_EINVAL, "a batch is pending or a stream is open");
     if (width < 1 || height < 1 || (uint64_t)width * height >= (1ull << 28)) return fail(ctx, H2Y_EINVAL, "bad picture size");
     if (in_bit_depth < 8 || in_bit_depth > 16 || out_bit_depth < 8 || out_bit_depth > 16) return fail(ctx, H2Y_EINVAL, "bit depths must be 8..16");
     if (in_matrix_coeffs == H2Y_MATRIX_GBR) /* convert.cpp:1733-1736: "Can't determine color difference to use?" and exit(0) */
@@ -1189,13 +1218,13 @@ int h2y_matrix_inverse(h2y_ctx *ctx, int width, int height, int in_bit_depth, in
     uint32_t blocks = (a.npix / 4 + 255) / 256;
     if (blocks > (uint32_t)ctx->n_cu * 16u) blocks = (uint32_t)ctx->n_cu * 16u;
     if (blocks < 1) blocks = 1;
-    ctx->n_ev = 0;
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[0][0], ctx->stream));
+    ctx->b->n_ev = 0;
+    HIP_TRY(ctx, hipEventRecord(ctx->b->ev[0][0], ctx->stream));
     HIP_TRY(ctx, h2y_launch_inverse((int)blocks, ctx->stream, a));
-    HIP_TRY(ctx, hipEventRecord(ctx->ev[0][1], ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ctx->b->ev[0][1], ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     float ms = 0.f;
-    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0][0], ctx->ev[0][1]));
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->b->ev[0][0], ctx->b->ev[0][1]));
     ctx->last_ms = ms;
     ctx->last_launches = 1;
     ctx->last_name = "k_inverse";
@@ -1220,7 +1249,7 @@ int h2y_upsample_444(h2y_ctx *ctx, int width, int height, int algorithm, unsigne
                      uint16_t *d_dst)
 {
     if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
-    if (ctx->pending || ctx->streaming) return fail(ctx, H2Y_EINVAL, "a batch is pending or a stream is open");
+    if ((ctx->q_count > 0) || ctx->streaming) return fail(ctx, H2Y_EINVAL, "a batch is pending or a stream is open");
     /* odd sizes: the reference's FIR branch reads rows of its intermediate it never wrote (convert.cpp:1949 walks
      * j < height over 2 * (height / 2) written rows): no defined bytes */
     if (width < 2 || height < 2 || (width & 1) || (height & 1) || width > 32766 || height > 32766)
@@ -1238,7 +1267,7 @@ int h2y_inverse_420(h2y_ctx *ctx, int width, int height, int in_bit_depth, int i
                     int algorithm, const uint16_t *const d_in[3], uint16_t *const d_out[3])
 {
     if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
-    if (ctx->pending || ctx->streaming) return fail(ctx, H2Y_EINVAL, "a batch is pending or a stream is open");
+    if ((ctx->q_count > 0) || ctx->streaming) return fail(ctx, H2Y_EINVAL, "a batch is pending or a stream is open");
     if (width < 2 || height < 2 || (width & 3) || (height & 1) || width > 32766 || height > 32766)
         return fail(ctx, H2Y_EINVAL, "4:2:0 inverse: width a multiple of 4 and height even, up to 32766"); /* the upsampled planes feed 8-byte loads */
     if (in_bit_depth < 8 || in_bit_depth > 16) return fail(ctx, H2Y_EINVAL, "bit depths must be 8..16");
@@ -1283,7 +1312,7 @@ static void stream_free(h2y_ctx *ctx)
 int h2y_stream_open(h2y_ctx *ctx, const h2y_desc *d, int depth)
 {
     if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
-    if (ctx->pending || ctx->streaming) return fail(ctx, H2Y_EINVAL, "a batch is pending or a stream is already open");
+    if ((ctx->q_count > 0) || ctx->streaming) return fail(ctx, H2Y_EINVAL, "a batch is pending or a stream is already open");
     const char *why;
     int rc = h2y_desc_check(d, &why);
     if (rc) return fail(ctx, rc, "descriptor: %s", why);
@@ -1348,7 +1377,7 @@ int h2y_stream_submit(h2y_ctx *ctx)
     const bool needs_stats = d->src_transfer != d->dst_transfer;
     int rc;
     if (needs_stats && !d->stats_override) {
-        rc = run_stats(ctx, d, io.in, (int)ctx->frames_cap, ctx->d_assumed); /* published in device memory, read by the next kernel */
+        rc = run_stats(ctx, d, io.in, (int)ctx->b->frames_cap, ctx->b->d_assumed); /* published in device memory, read by the next kernel */
         if (rc) return rc;
     } else {
         /* the same six integers for every frame of the stream: staged once per slot, so an earlier copy still in flight reads its own */
@@ -1357,12 +1386,12 @@ int h2y_stream_submit(h2y_ctx *ctx)
             as->floor_[c] = d->stats_override ? d->floor[c] : 0;
             as->ceil_[c] = d->stats_override ? d->ceiling[c] : 1;
         }
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->d_assumed, as, sizeof *as, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->b->d_assumed, as, sizeof *as, hipMemcpyHostToDevice, ctx->stream));
     }
     ctx->slot_base = slot;
-    ctx->n_ev = 0;
+    ctx->b->n_ev = 0;
     ctx->cur_skip_t1 = false; /* PCIe-bound here: no steering between the tiers */
-    rc = run_frames(ctx, d, &io, 1, ctx->d_assumed, nullptr, false, slot, false);
+    rc = run_frames(ctx, d, &io, 1, ctx->b->d_assumed, nullptr, false, slot, false);
     ctx->slot_base = 0;
     if (rc) return rc;
     HIP_TRY(ctx, hipEventRecord(s.ev_conv, ctx->stream));
@@ -1409,7 +1438,7 @@ int h2y_stream_close(h2y_ctx *ctx)
 int h2y_pic_stats(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3], float fminmax[6], int32_t floor_ceiling[6])
 {
     if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
-    if (ctx->pending) return fail(ctx, H2Y_EINVAL, "a batch is pending");
+    if ((ctx->q_count > 0)) return fail(ctx, H2Y_EINVAL, "a batch is pending");
     if (ctx->streaming) return fail(ctx, H2Y_EINVAL, "a stream is open: close it first");
     const char *why;
     int rc = h2y_desc_check(d, &why);
@@ -1418,10 +1447,10 @@ int h2y_pic_stats(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3], fl
     for (int c = 0; c < 3; c++) /* run_stats() takes the scalar-load path for planes that are not 16-byte aligned */
         if (!d_in[c] || ((uintptr_t)d_in[c] & (sample_bytes(d) - 1))) return fail(ctx, H2Y_EINVAL, "input plane %d is null or not aligned to its sample size", c);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    rc = run_stats(ctx, d, d_in, (int)ctx->frames_cap, nullptr);
+    rc = run_stats(ctx, d, d_in, (int)ctx->b->frames_cap, nullptr);
     if (rc) return rc;
-    frame_stats *hs = ctx->h_fstats + ctx->frames_cap;
-    HIP_TRY(ctx, hipMemcpyAsync(hs, ctx->d_fstats + ctx->frames_cap, sizeof(frame_stats), hipMemcpyDeviceToHost, ctx->stream));
+    frame_stats *hs = ctx->b->h_fstats + ctx->b->frames_cap;
+    HIP_TRY(ctx, hipMemcpyAsync(hs, ctx->b->d_fstats + ctx->b->frames_cap, sizeof(frame_stats), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     for (int i = 0; i < 6; i++) fminmax[i] = hs->mm[i];
     for (int c = 0; c < 3; c++) {
@@ -1434,7 +1463,7 @@ int h2y_pic_stats(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3], fl
 int h2y_matrix_convert(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3], uint16_t *const d_out444[3])
 {
     if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
-    if (ctx->pending) return fail(ctx, H2Y_EINVAL, "a batch is pending");
+    if ((ctx->q_count > 0)) return fail(ctx, H2Y_EINVAL, "a batch is pending");
     if (ctx->streaming) return fail(ctx, H2Y_EINVAL, "a stream is open: close it first");
     const char *why;
     int rc = h2y_desc_check(d, &why);
@@ -1445,7 +1474,7 @@ int h2y_matrix_convert(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3
         if (!d_out444[c] || ((uintptr_t)d_out444[c] & 15)) return fail(ctx, H2Y_EINVAL, "output plane %d is null or not 16-byte aligned", c);
     }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    assumed_stats *as = ctx->h_assumed;
+    assumed_stats *as = ctx->b->h_assumed;
     for (int c = 0; c < 3; c++) {
         as->floor_[c] = d->floor[c];
         as->ceil_[c] = d->ceiling[c];
@@ -1453,7 +1482,7 @@ int h2y_matrix_convert(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3
     if (d->src_transfer != d->dst_transfer)
         for (int c = 0; c < 3; c++)
             if (d->floor[c] == d->ceiling[c]) return fail(ctx, H2Y_EINVAL, "floor == ceiling for plane %d", c);
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_assumed, as, sizeof *as, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->b->d_assumed, as, sizeof *as, hipMemcpyHostToDevice, ctx->stream));
     pix_params pp;
     derive_params(d, &pp, true);
     fused_variant var;
@@ -1469,14 +1498,14 @@ int h2y_matrix_convert(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3
     io.out = d_out444[0];
     io.tmp_cb = d_out444[1];
     io.tmp_cr = d_out444[2];
-    ctx->h_frames[0] = io;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->d_frames, ctx->h_frames, sizeof(frame_io), hipMemcpyHostToDevice, ctx->stream));
-    ctx->dev_frames.clear(); /* run_frames()'s record of what d_frames holds */
+    ctx->b->h_frames[0] = io;
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->b->d_frames, ctx->b->h_frames, sizeof(frame_io), hipMemcpyHostToDevice, ctx->stream));
+    ctx->b->dev_frames.clear(); /* run_frames()'s record of what d_frames holds */
     const int grid = grid_for(ctx, var, g.chunks);
-    rc = ensure(ctx, ctx->d_partial, ctx->partial_cap, (size_t)grid * (h2y_fused_threads(var) / 64) * 6 * sizeof(float));
+    rc = ensure(ctx, ctx->b->d_partial, ctx->b->partial_cap, (size_t)grid * (h2y_fused_threads(var) / 64) * 6 * sizeof(float));
     if (rc) return rc;
     fused_args a;
-    a.frames = ctx->d_frames;
+    a.frames = ctx->b->d_frames;
     a.n_frames = 1;
     a.width = d->width;
     a.height = d->height;
@@ -1496,8 +1525,8 @@ int h2y_matrix_convert(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3
     a.tiles_magic = 0;
     a.redo_count = nullptr;
     a.low_flag = nullptr;
-    a.partial = ctx->d_partial;
-    a.assumed = ctx->d_assumed;
+    a.partial = ctx->b->d_partial;
+    a.assumed = ctx->b->d_assumed;
     a.pp = pp;
     HIP_TRY(ctx, h2y_launch_fused(var, grid, ctx->stream, a));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1508,7 +1537,7 @@ int h2y_subsample_420(h2y_ctx *ctx, int width, int height, int bit_depth, int ch
                       uint16_t *d_dst)
 {
     if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
-    if (ctx->pending) return fail(ctx, H2Y_EINVAL, "a batch is pending");
+    if ((ctx->q_count > 0)) return fail(ctx, H2Y_EINVAL, "a batch is pending");
     if (ctx->streaming) return fail(ctx, H2Y_EINVAL, "a stream is open: close it first");
     if (width < 2 || height < 2 || (width & 1) || (height & 1) || bit_depth < 8 || bit_depth > 16 || !d_src || !d_dst)
         return fail(ctx, H2Y_EINVAL, "bad subsample arguments");

@@ -153,9 +153,15 @@ int h2y_convert_batch(h2y_ctx *ctx, const h2y_desc *d, int n_frames,
 
 /* As h2y_convert_batch but enqueue-only: no host synchronisation and no
  * status read-back.  h2y_batch_finish() must be called before the outputs
- * are consumed: it waits, checks the per-frame floor/ceiling the kernels
- * measured against the ones they assumed, and re-runs any frame where they
- * differ.  Returns the number of frames re-run through *n_redone. */
+ * are consumed: it waits for the OLDEST batch in flight, checks the per-frame
+ * floor/ceiling the kernels measured against the ones they assumed, and
+ * re-runs any frame where they differ.  Returns the number of frames re-run
+ * through *n_redone.
+ * Up to TWO batches may be in flight: enqueue k+1 before finishing k and the
+ * next launch is already queued behind the running one (no idle gap between
+ * them).  A batch's input and output buffers belong to the library until its
+ * own h2y_batch_finish() returns; batches finish in the order enqueued.
+ * h2y_convert_batch() finishes everything in flight, its own batch last. */
 int h2y_convert_batch_enqueue(h2y_ctx *ctx, const h2y_desc *d, int n_frames,
                               const void *const *d_in, uint16_t *const *d_out);
 int h2y_batch_finish(h2y_ctx *ctx, int *n_redone);

@@ -1008,3 +1008,49 @@ def test_fir_fused_kernel_geometries(oracle, w, hh):
     finally:
         if fresh is not None:
             fresh.close()
+
+
+@pytest.mark.parametrize("res", [0, 1])
+def test_two_batches_in_flight(oracle, res):
+    """h2y_convert_batch_enqueue twice before the first h2y_batch_finish: the second launch is queued behind the
+    first; batches finish in order, each with its own statistics check (one frame of EACH batch breaks the hint and
+    is redone while the other batch may still be running), a third enqueue is refused, and a stage entry in between
+    is refused too."""
+    import torch
+
+    rng = np.random.default_rng(2002 + res)
+    w, hh = 512, 96
+    d = h.make_desc(w, hh, dst_depth=12, dst_matrix=h.MATRIX_BT2020NC, resampler=res)
+    od = _to_oracle_desc(d)
+    batches = []
+    for b in range(4):
+        host = [_rand_planes(rng, w, hh, h.SAMPLE_F32) for _ in range(8)]
+        if b in (1, 2):
+            host[b + 2][1][77] = np.float32(2.5)  # ceiling 2: this frame is redone
+        dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in host]
+        dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda") for _ in host]
+        batches.append((host, dev_in, dev_out))
+    torch.cuda.synchronize()
+    c = h.Context(0)
+    if res:
+        c.set_option("fir", "fused")
+    try:
+        c.convert_batch(d, batches[0][1], batches[0][2])  # establishes the hint
+        c.convert_batch_enqueue(d, batches[1][1], batches[1][2])
+        c.convert_batch_enqueue(d, batches[2][1], batches[2][2])
+        with pytest.raises(h.H2YError):
+            c.convert_batch_enqueue(d, batches[3][1], batches[3][2])
+        with pytest.raises(h.H2YError):
+            c.pic_stats(d, batches[3][1][0])
+        assert c.batch_finish() == 1
+        c.convert_batch_enqueue(d, batches[3][1], batches[3][2])  # a slot is free again
+        assert c.batch_finish() == 1
+        assert c.batch_finish() == 0
+        assert c.batch_finish() == 0  # nothing in flight: a no-op
+        for b, (host, _, dev_out) in enumerate(batches):
+            for f in range(len(host)):
+                got = dev_out[f].cpu().numpy().view(np.uint16)
+                want = oracle.convert_frame(od, host[f])
+                assert np.array_equal(got, want), f"batch {b} frame {f}: {np.count_nonzero(got != want)} samples differ"
+    finally:
+        c.close()

@@ -72,6 +72,7 @@ def parse(argv=None):
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="h2y_ctx_set_option knobs (A/B timing), e.g. fir=twopass")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (nccl = RCCL; gloo only to rehearse N > 1)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--no-pipeline", action="store_true", help="finish every step before the next is enqueued (A/B against two batches in flight)")
     ap.add_argument("--rehearse", action="store_true",
                     help="CPU rehearsal of the N-rank launch: ranks rendezvous (gloo), shard the frame indices and reduce made-up counters; "
                          "no device, no conversion, nothing measured")
@@ -138,7 +139,7 @@ class DeviceSynth:
         return planes
 
 
-def run_steps(ctx, d, n_frames, ins, outs, steps, warmup, barrier):
+def run_steps(ctx, d, n_frames, ins, outs, steps, warmup, barrier, pipeline=True):
     """W untimed + K timed steps. Returns (seconds for K steps, mean kernel ms per step, redone frames, launches per step)."""
     import torch
 
@@ -155,11 +156,11 @@ def run_steps(ctx, d, n_frames, ins, outs, steps, warmup, barrier):
     # launches follow each other without a gap (same stream: the kernels never overlap, each one's HIP events are its own)
     for k in range(steps):
         ctx.convert_batch_enqueue_raw(d, n_frames, ins, outs)
-        if k > 0:
+        if k > 0 or not pipeline:
             redone += ctx.batch_finish()
             ms, launches = ctx.last_kernel_ms()
             kms += ms
-    if steps > 0:
+    if steps > 0 and pipeline:
         redone += ctx.batch_finish()
         ms, launches = ctx.last_kernel_ms()
         kms += ms
@@ -349,7 +350,7 @@ def main() -> int:
         outs_t = [torch.empty(nb // 2, dtype=torch.int16, device=dev) for _ in range(F)]
         ins = (C.c_void_p * (3 * F))(*[t.data_ptr() for i in range(F) for t in frames_in[i % len(frames_in)]])
         outs = (C.c_void_p * F)(*[t.data_ptr() for t in outs_t])
-        secs, kernel_ms, redone, launches = run_steps(ctx, d, F, ins, outs, steps, warmup, barrier)
+        secs, kernel_ms, redone, launches = run_steps(ctx, d, F, ins, outs, steps, warmup, barrier, not args.no_pipeline)
         mine = torch.tensor([secs, float(F) * w * hh * steps], dtype=torch.float64, device=red_dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         if world > 1:

@@ -81,7 +81,11 @@ struct batch_state {
     uint32_t bal_used_mask = 0xFFu;
     double bal_used_extra = 0.0;              /* work of a fast block relative to a slow one, minus one, in that launch */
     frame_stats *d_fstats = nullptr, *h_fstats = nullptr;
+    frame_stats *m_fstats = nullptr; /* h_fstats as the device sees it (pinned host memory): k_stats_final of a batch writes there, no copy command */
+    frame_stats *fs_out = nullptr;   /* where run_frames() has the statistics written: d_fstats, or m_fstats for an enqueued batch */
     assumed_stats *d_assumed = nullptr, *h_assumed = nullptr; /* [2]: [0] batch, [1] redo */
+    assumed_stats dev_assumed;       /* what d_assumed[0] holds when dev_assumed_ok (one small copy command less per batch) */
+    bool dev_assumed_ok = false;
     /* the batch itself, between enqueue and finish */
     h2y_desc p_desc;
     int p_n = 0;
@@ -527,7 +531,7 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
             fin.nblk = (int)upf;
             fin.redo_count = ctx->b->d_redo;
             fin.low_flag = ident ? ctx->b->d_low : nullptr;
-            fin.out = ctx->b->d_fstats + fstats_offset;
+            fin.out = ctx->b->fs_out + fstats_offset;
             fin.is_u16 = 0;
             fin.src_bit_depth = d->src_bit_depth;
             fin.check = check ? 1 : 0;
@@ -662,7 +666,7 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         fa.nblk = grid / groups * waves;
         fa.redo_count = t1 ? ctx->b->d_redo : nullptr;
         fa.low_flag = approx ? ctx->b->d_low : nullptr;
-        fa.out = ctx->b->d_fstats + fstats_offset + f0;
+        fa.out = ctx->b->fs_out + fstats_offset + f0;
         fa.is_u16 = d->in_sample_type == H2Y_SAMPLE_U16;
         fa.src_bit_depth = d->src_bit_depth;
         fa.check = check ? 1 : 0;
@@ -671,7 +675,7 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         fa.block_clock = clocks ? ctx->b->d_clock : nullptr;
         fa.grid = grid;
         static_assert(sizeof(frame_stats) >= 8 * sizeof(float), "the XCD run times ride in one frame_stats entry");
-        fa.xcd_time = reinterpret_cast<float *>(ctx->b->d_fstats + fstats_offset + n); /* the caller's copy of the statistics takes one entry more */
+        fa.xcd_time = reinterpret_cast<float *>(ctx->b->fs_out + fstats_offset + n); /* the caller's copy of the statistics takes one entry more */
         HIP_TRY(ctx, h2y_launch_stats_final(nf, ctx->stream, fa));
         if (clocks) {
             ctx->b->bal_slot = fstats_offset + n;
@@ -719,6 +723,8 @@ int reserve_batch(h2y_ctx *ctx, int n)
         /* +1: slot for the stats pre-pass / redo */
         HIP_TRY(ctx, hipMalloc((void **)&ctx->b->d_fstats, (cap + 1) * sizeof(frame_stats)));
         HIP_TRY(ctx, hipHostMalloc((void **)&ctx->b->h_fstats, (cap + 1) * sizeof(frame_stats), hipHostMallocDefault));
+        HIP_TRY(ctx, hipHostGetDevicePointer((void **)&ctx->b->m_fstats, ctx->b->h_fstats, 0));
+        ctx->b->fs_out = ctx->b->d_fstats;
         ctx->b->frames_cap = cap;
     }
     return 0;
@@ -1021,30 +1027,44 @@ int h2y_convert_batch_enqueue(h2y_ctx *ctx, const h2y_desc *d, int n_frames, con
     bool host_knows = true;
     assumed_stats *as = ctx->b->h_assumed;
     if (!needs_stats || d->stats_override) {
+        assumed_stats want;
         for (int c = 0; c < 3; c++) {
-            as->floor_[c] = d->stats_override ? d->floor[c] : 0;
-            as->ceil_[c] = d->stats_override ? d->ceiling[c] : 1;
+            want.floor_[c] = d->stats_override ? d->floor[c] : 0;
+            want.ceil_[c] = d->stats_override ? d->ceiling[c] : 1;
         }
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->b->d_assumed, as, sizeof *as, hipMemcpyHostToDevice, ctx->stream));
+        if (!ctx->b->dev_assumed_ok || memcmp(&want, &ctx->b->dev_assumed, sizeof want) != 0) {
+            *as = want;
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->b->d_assumed, as, sizeof *as, hipMemcpyHostToDevice, ctx->stream));
+            ctx->b->dev_assumed = want;
+            ctx->b->dev_assumed_ok = true;
+        } else *as = want;
     } else if (ctx->have_hint && ctx->hint_kind == d->in_sample_type) {
         /* assume this batch looks like the last frame we saw; verified below */
+        assumed_stats want;
         for (int c = 0; c < 3; c++) {
-            as->floor_[c] = ctx->hint_floor[c];
-            as->ceil_[c] = ctx->hint_ceil[c];
+            want.floor_[c] = ctx->hint_floor[c];
+            want.ceil_[c] = ctx->hint_ceil[c];
         }
-        HIP_TRY(ctx, hipMemcpyAsync(ctx->b->d_assumed, as, sizeof *as, hipMemcpyHostToDevice, ctx->stream));
+        if (!ctx->b->dev_assumed_ok || memcmp(&want, &ctx->b->dev_assumed, sizeof want) != 0) {
+            *as = want;
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->b->d_assumed, as, sizeof *as, hipMemcpyHostToDevice, ctx->stream));
+            ctx->b->dev_assumed = want;
+            ctx->b->dev_assumed_ok = true;
+        } else *as = want; /* (the host copy is what pick_variant() reads) */
         check = true;
     } else {
         /* no history: measure frame 0 (pic_stats pre-pass) and assume the rest match it */
+        ctx->b->dev_assumed_ok = false;
         rc = run_stats(ctx, d, ctx->b->p_frames[0].in, (int)ctx->b->frames_cap, ctx->b->d_assumed);
         if (rc) return rc;
         check = true;
         host_knows = false; /* the values exist only in device memory */
     }
     t1_begin_batch(ctx);
+    ctx->b->fs_out = ctx->b->m_fstats; /* the statistics (+ the XCD run times) go straight to pinned host memory */
     rc = run_frames(ctx, d, ctx->b->p_frames.data(), n_frames, ctx->b->d_assumed, host_knows ? ctx->b->h_assumed : nullptr, check, 0, true);
+    ctx->b->fs_out = ctx->b->d_fstats;
     if (rc) return rc;
-    HIP_TRY(ctx, hipMemcpyAsync(ctx->b->h_fstats, ctx->b->d_fstats, ((size_t)n_frames + 1) * sizeof(frame_stats), hipMemcpyDeviceToHost, ctx->stream)); /* + the XCD run times */
     HIP_TRY(ctx, hipEventRecord(ctx->b->ev_done, ctx->stream));
     ctx->b->p_desc = *d;
     ctx->b->p_n = n_frames;
@@ -1160,6 +1180,7 @@ int h2y_convert_frame(h2y_ctx *ctx, const h2y_desc *d, const void *const in_plan
     bool host_knows = true;
     if (needs_stats && !d->stats_override) {
         rc = run_stats(ctx, d, io.in, (int)ctx->b->frames_cap, ctx->b->d_assumed);
+        ctx->b->dev_assumed_ok = false; /* d_assumed[0] no longer holds what the last enqueued batch left there */
         if (rc) return rc;
         host_knows = false;
     } else {
@@ -1169,6 +1190,7 @@ int h2y_convert_frame(h2y_ctx *ctx, const h2y_desc *d, const void *const in_plan
             as->ceil_[c] = d->stats_override ? d->ceiling[c] : 1;
         }
         HIP_TRY(ctx, hipMemcpyAsync(ctx->b->d_assumed, as, sizeof *as, hipMemcpyHostToDevice, ctx->stream));
+        ctx->b->dev_assumed_ok = false; /* d_assumed[0] no longer holds what the last enqueued batch left there */
     }
     ctx->b->n_ev = 0;
     t1_begin_batch(ctx);
@@ -1378,6 +1400,7 @@ int h2y_stream_submit(h2y_ctx *ctx)
     int rc;
     if (needs_stats && !d->stats_override) {
         rc = run_stats(ctx, d, io.in, (int)ctx->b->frames_cap, ctx->b->d_assumed); /* published in device memory, read by the next kernel */
+        ctx->b->dev_assumed_ok = false; /* d_assumed[0] no longer holds what the last enqueued batch left there */
         if (rc) return rc;
     } else {
         /* the same six integers for every frame of the stream: staged once per slot, so an earlier copy still in flight reads its own */
@@ -1387,6 +1410,7 @@ int h2y_stream_submit(h2y_ctx *ctx)
             as->ceil_[c] = d->stats_override ? d->ceiling[c] : 1;
         }
         HIP_TRY(ctx, hipMemcpyAsync(ctx->b->d_assumed, as, sizeof *as, hipMemcpyHostToDevice, ctx->stream));
+        ctx->b->dev_assumed_ok = false; /* d_assumed[0] no longer holds what the last enqueued batch left there */
     }
     ctx->slot_base = slot;
     ctx->b->n_ev = 0;
@@ -1483,6 +1507,7 @@ int h2y_matrix_convert(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3
         for (int c = 0; c < 3; c++)
             if (d->floor[c] == d->ceiling[c]) return fail(ctx, H2Y_EINVAL, "floor == ceiling for plane %d", c);
     HIP_TRY(ctx, hipMemcpyAsync(ctx->b->d_assumed, as, sizeof *as, hipMemcpyHostToDevice, ctx->stream));
+    ctx->b->dev_assumed_ok = false; /* d_assumed[0] no longer holds what the last enqueued batch left there */
     pix_params pp;
     derive_params(d, &pp, true);
     fused_variant var;

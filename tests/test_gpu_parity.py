@@ -433,6 +433,7 @@ def test_caller_stream(ctx, oracle):
         with torch.cuda.stream(st):
             dev_in = [[torch.from_numpy(p).cuda(non_blocking=False) for p in planes]]
             dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda")]
+            torch.cuda.synchronize()  # the context's stream does not wait for torch's
         st.synchronize()
         fresh.convert_batch(d, dev_in, dev_out)
         assert np.array_equal(dev_out[0].cpu().numpy().view(np.uint16), oracle.convert_frame(_to_oracle_desc(d), planes))
@@ -578,6 +579,7 @@ def test_matrix_inverse(ctx, oracle):
                     p[:5] = [0, (1 << ind) - 1, 1 << (ind - 1), (1 << (ind - 1)) - 1, 1]
                 din = [torch.from_numpy(p.view(np.int16)).cuda() for p in planes]
                 dout = [torch.zeros(n, dtype=torch.int16, device="cuda") for _ in range(3)]
+                torch.cuda.synchronize()  # the context's stream does not wait for torch's
                 ctx.matrix_inverse(w, hh, ind, full, mat, outd, din, dout)
                 want = oracle.matrix_inverse(w, hh, ind, full, mat, outd, planes)
                 for c in range(3):
@@ -669,6 +671,7 @@ def test_fuzz_descriptors_against_oracle(ctx, oracle):
             conv = (lambda p: torch.from_numpy(p.view(np.int16) if p.dtype == np.uint16 else p).cuda())
             dev_in = [[conv(np.ascontiguousarray(p)) for p in fr] for fr in frames]
             dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda") for _ in frames]
+            torch.cuda.synchronize()  # the context's stream does not wait for torch's
             ctx.convert_batch(d, dev_in, dev_out)
             got = [t.cpu().numpy().view(np.uint16) for t in dev_out]
         for f, planes in enumerate(frames):
@@ -698,6 +701,7 @@ def test_tier_steering_on_black_frames(oracle):
             planes = black if step < 11 else noise
             dev_in = [[torch.from_numpy(p).cuda() for p in planes] for _ in range(2)]
             dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda") for _ in range(2)]
+            torch.cuda.synchronize()  # the context's stream does not wait for torch's
             c.convert_batch(d, dev_in, dev_out)
             names.append(c.last_kernel_name())
             for t in dev_out:
@@ -731,6 +735,7 @@ def test_subsampled_minimum_cases(oracle):
         p[1, 2] = np.float32(0.25)                       # ... but the picture's minimum is not
     dev_in = [[torch.from_numpy(np.ascontiguousarray(p)).cuda() for p in fr] for fr in host]
     dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda") for _ in host]
+    torch.cuda.synchronize()  # the context's stream does not wait for torch's
     c = h.Context(0)
     try:
         c.convert_batch(d, dev_in[:2], dev_out[:2])       # establishes the hint floor 0 / ceiling 1
@@ -930,6 +935,7 @@ def test_upsample_444(ctx, oracle, w, hh):
         for alg in (0, 1, 7):
             for (lo, hi) in ((0, maxcv), (16 << (depth - 8), 240 << (depth - 8))):
                 ddst = torch.zeros(hh * w, dtype=torch.int16, device="cuda")
+                torch.cuda.synchronize()  # the context's stream does not wait for torch's
                 ctx.upsample_444(w, hh, alg, lo, hi, dsrc, ddst)
                 got = ddst.cpu().numpy().view(np.uint16).reshape(hh, w)
                 want = oracle.up444(src, w, hh, alg, lo, hi)
@@ -951,6 +957,7 @@ def test_inverse_420_flow(ctx, oracle):
             cr = rng.integers(0, 1 << ind, n // 4).astype(np.uint16)
             din = [torch.from_numpy(p.view(np.int16)).cuda() for p in (y, cb, cr)]
             dout = [torch.zeros(n, dtype=torch.int16, device="cuda") for _ in range(3)]
+            torch.cuda.synchronize()  # the context's stream does not wait for torch's
             ctx.inverse_420(w, hh, ind, full, mat, outd, alg, din, dout)
             maxcv = (1 << ind) - 1
             full_planes = [y, oracle.up444(cb, w, hh, alg, 0, maxcv).reshape(-1), oracle.up444(cr, w, hh, alg, 0, maxcv).reshape(-1)]

@@ -798,8 +798,6 @@ int h2y_desc_check(const h2y_desc *d, const char **why)
     if (d->src_transfer != d->dst_transfer) {
         if (tf_class(d->src_transfer) < 0) BAD(H2Y_EUNSUPPORTED, "src_transfer_characteristics not supported (yet)");  /* convert.cpp:1061 */
         if (tf_class(d->dst_transfer) < 0) BAD(H2Y_EUNSUPPORTED, "dst_transfer_characteristics not supported (yet)");  /* convert.cpp:1107 */
-        if (tf_class(d->src_transfer) == H2Y_TF_RHO_GAMMA)
-            BAD(H2Y_EUNSUPPORTED, "RHO_GAMMA as the source goes through powf(), whose libm rounding cannot be reproduced bit for bit");
     }
     if (!(d->dst_matrix == d->src_matrix && d->dst_primaries == d->src_primaries)) {
         switch (d->dst_matrix) {

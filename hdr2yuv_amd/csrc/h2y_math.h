@@ -251,6 +251,96 @@ H2Y_FN double pow_gen(double x, double y)
     if (x > 1.7976931348623157e308) return x; /* +inf */
     return pow_dd(x, y);
 }
+/* ------------------------------------------------------------------------
+ * powf(25.0f, y) as glibc computes it.
+ *
+ * RHO_GAMMA_f (convert.cpp:23) calls pow(float rho, float V): in C++ that is powf, and glibc's powf is not a
+ * correctly rounded function -- its float depends on its algorithm (0.06 % of results differ from the correctly
+ * rounded value).  So that algorithm is restated here: glibc 2.28+ sysdeps/ieee754/flt-32/e_powf.c (Szabolcs
+ * Nagy's ARM optimized routines), in the form the x86-64 FMA build runs (libm's ifunc picks __powf_fma wherever the
+ * CPU has FMA; every multiply-add of the source is one fused operation there, the product y * log2(x) is not --
+ * read off the machine code of glibc 2.35).  x is always 25.0f here, so log2(x) is a constant of the algorithm: its
+ * table entry and the degree-4 polynomial, evaluated by powf_log2_of_25() the way the function does.  tools/pq_check powf compares with this machine's powf over every float of [0, 1] and
+ * sampled wider ranges (tests/test_pq_math.py).  A host without FMA runs glibc's unfused build and may round a few
+ * results the other way; the reference's bytes then differ too (parity follows the FMA build, which is what both
+ * this container and the GPU boxes' hosts run).
+ * ---------------------------------------------------------------------- */
+H2Y_FN double powf_log2_of_25(void)
+{
+    /* log2_inline(asuint(25.0f)): OFF = 0x3f330000, 16 subintervals; tmp = ix - OFF, i = (tmp >> 19) % 16,
+     * top = tmp & 0xff800000, z = asfloat(ix - top), k = top >> 23 */
+    const uint32_t ix = 0x41C80000u, tmp = ix - 0x3f330000u;
+    const int i = (int)((tmp >> 19) & 15u);
+    const uint32_t top = tmp & 0xff800000u;
+    const double z = (double)bits2f(ix - top);
+    const double k = (double)((int32_t)top >> 23);
+    /* __powf_log2_data.tab[i] = {invc, logc} */
+    const double invc[16] = {0x1.661ec79f8f3bep+0, 0x1.571ed4aaf883dp+0, 0x1.49539f0f010bp+0, 0x1.3c995b0b80385p+0, 0x1.30d190c8864a5p+0,
+                             0x1.25e227b0b8eap+0,  0x1.1bb4a4a1a343fp+0, 0x1.12358f08ae5bap+0, 0x1.0953f419900a7p+0, 0x1p+0,
+                             0x1.e608cfd9a47acp-1, 0x1.ca4b31f026aap-1,  0x1.b2036576afce6p-1, 0x1.9c2d163a1aa2dp-1, 0x1.886e6037841edp-1,
+                             0x1.767dcf5534862p-1};
+    const double logc[16] = {-0x1.efec65b963019p-2, -0x1.b0b6832d4fca4p-2, -0x1.7418b0a1fb77bp-2, -0x1.39de91a6dcf7bp-2, -0x1.01d9bf3f2b631p-2,
+                             -0x1.97c1d1b3b7afp-3,  -0x1.2f9e393af3c9fp-3, -0x1.960cbbf788d5cp-4, -0x1.a6f9db6475fcep-5, 0x0p+0,
+                             0x1.338ca9f24f53dp-4,  0x1.476a9543891bap-3,  0x1.e840b4ac4e4d2p-3,  0x1.40645f0c6651cp-2,  0x1.88e9c2c1b9ff8p-2,
+                             0x1.ce0a44eb17bccp-2};
+    const double A0 = 0x1.27616c9496e0bp-2, A1 = -0x1.71969a075c67ap-2, A2 = 0x1.ec70a6ca7baddp-2, A3 = -0x1.7154748bef6c8p-1,
+                 A4 = 0x1.71547652ab82bp+0;
+    const double r = __builtin_fma(z, invc[i], -1.0);
+    const double y0 = logc[i] + k;
+    const double r2 = r * r;
+    double y = __builtin_fma(A0, r, A1);
+    const double p = __builtin_fma(A2, r, A3);
+    const double r4 = r2 * r2;
+    double q = __builtin_fma(A4, r, y0);
+    q = __builtin_fma(p, r2, q);
+    y = __builtin_fma(y, r4, q);
+    return y;
+}
+/* 2^(i/32) as asuint64(2^(i/32)) - (i << 47): __exp2f_data.tab */
+H2Y_FN uint64_t exp2f_tab(uint32_t i)
+{
+    const uint64_t T[32] = {
+        0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull, 0x3fef54873168b9aaull,
+        0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+        0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull,
+        0x3feea11473eb0187ull, 0x3feea589994cce13ull, 0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+        0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
+        0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+    return T[i & 31u];
+}
+H2Y_FN float powf25(float yf)
+{
+    const uint32_t iy = f2bits(yf);
+    if (2u * iy - 1u >= 2u * 0x7f800000u - 1u) { /* zeroinfnan(iy): y is 0, inf or NaN */
+        if (2u * iy == 0u) return 1.0f;
+        if (2u * iy > 2u * 0x7f800000u) return yf + yf; /* NaN */
+        return (iy & 0x80000000u) ? 0.0f : yf * yf;     /* |x| > 1: y = -inf gives 0, +inf gives inf */
+    }
+    const double logx = powf_log2_of_25();
+    const double ylogx = (double)yf * logx; /* its own rounding: not fused with what follows */
+    if (((d2bits(ylogx) >> 47) & 0xffffu) >= (d2bits(126.0) >> 47)) { /* |y log2 x| >= 126 */
+        if (ylogx > 0x1.fffffffd1d571p+6) return bits2f(0x7F800000u); /* overflow */
+        if (ylogx <= -150.0) return 0.0f;                              /* underflow */
+        if (ylogx < -149.0) return bits2f(1u);                         /* __math_may_uflowf: 0x1.4p-75f squared rounds to the smallest subnormal */
+    }
+    /* exp2_inline: x = k/32 + r, |r| <= 1/64 */
+    const double SHIFT = 0x1.8p+47; /* __exp2f_data.shift_scaled */
+    double kd = ylogx + SHIFT;
+    const uint64_t ki = d2bits(kd);
+    kd -= SHIFT;
+    const double r = ylogx - kd;
+    uint64_t t = exp2f_tab((uint32_t)ki);
+    t += ki << 47; /* 52 - EXP2F_TABLE_BITS */
+    const double s = bits2d(t);
+    const double C0 = 0x1.c6af84b912394p-5, C1 = 0x1.ebfce50fac4f3p-3, C2 = 0x1.62e42ff0c52d6p-1;
+    const double z = __builtin_fma(C0, r, C1);
+    const double r2 = r * r;
+    double y = __builtin_fma(C2, r, 1.0);
+    y = __builtin_fma(z, r2, y);
+    y = y * s;
+    return (float)y;
+}
+
 H2Y_FN float tf_to_linear(int cls, float V)
 {
     if (cls == H2Y_TF_PQ) { /* PQ10000_f, convert.cpp:43-51 */
@@ -259,9 +349,8 @@ H2Y_FN float tf_to_linear(int cls, float V)
         num = num > 0.0 ? num : 0.0; /* fmax(., 0.0): a NaN also gives 0.0 */
         return (float)pow_gen(num / (18.8515625 - 18.6875 * p), 1.0 / 0.1593017578);
     }
-    if (cls == H2Y_TF_RHO_GAMMA) { /* RHO_GAMMA_f, convert.cpp:12-27: inner pow is powf */
-        float P = (float)pow_gen(25.0, (double)V);
-        if (V < 0.0f) P = (float)(1.0 / pow_gen(25.0, -(double)V)); /* 25^V for negative V (unpinned domain) */
+    if (cls == H2Y_TF_RHO_GAMMA) { /* RHO_GAMMA_f, convert.cpp:12-27: the inner pow is powf (glibc's, restated above), the outer double */
+        const float P = powf25(V);
         return (float)pow_gen(((double)P - 1.0) / 24.0, (double)2.4f);
     }
     if (cls == H2Y_TF_BT1886) { /* bt1886_f, convert.cpp:67-75, a = 1, b = 0 */

@@ -57,7 +57,7 @@ def test_frame_and_plane_bytes():
     (dict(width=64, height=32, src_transfer=1, dst_transfer=16), 0),   # BT.709 (BT.1886) -> PQ: careful tier
     (dict(width=64, height=32, src_transfer=13, dst_transfer=16), 2),  # sRGB: the reference only prints a warning
     (dict(width=64, height=32, src_transfer=8, dst_transfer=9), 2),    # LOG1 as destination: same
-    (dict(width=64, height=32, src_transfer=18, dst_transfer=8), 2),   # RHO_GAMMA source: powf() rounding not reproducible
+    (dict(width=64, height=32, src_transfer=18, dst_transfer=8), 0),   # RHO_GAMMA source: glibc's powf algorithm, restated
     (dict(width=64, height=32, chroma=2), 2),             # 4:2:2 output
     (dict(width=64, height=32, sample=1, src_depth=10, dst_depth=12, src_transfer=16), 1),  # dst depth > src depth
     (dict(width=64, height=32, stats=[(0, 0), (0, 1), (0, 1)]), 1),   # zero range

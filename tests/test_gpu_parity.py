@@ -442,9 +442,11 @@ def test_caller_stream(ctx, oracle):
         fresh.close()
 
 
-@pytest.mark.parametrize("src,dst", [(16, 8), (8, 18), (1, 16), (8, 1), (16, 18), (6, 15), (14, 8), (8, 14), (1, 6), (15, 16)])
+@pytest.mark.parametrize("src,dst", [(16, 8), (8, 18), (1, 16), (8, 1), (16, 18), (6, 15), (14, 8), (8, 14), (1, 6), (15, 16), (18, 8), (18, 16),
+                                     (18, 1)])
 def test_other_transfer_pairs(ctx, oracle, src, dst):
-    """PQ10000_f, RHO_GAMMA_r, bt1886_f/_r at the same dispatch point (careful tier)."""
+    """PQ10000_f, RHO_GAMMA_f/_r, bt1886_f/_r at the same dispatch point (careful tier).  RHO_GAMMA as the
+    source goes through powf(25, V): glibc's algorithm restated (powf25, pinned over every float of [0, 1] on the CPU)."""
     rng = np.random.default_rng(50 + src * 19 + dst)
     w, hh = 96, 24
     planes = _rand_planes(rng, w, hh, h.SAMPLE_F32)
@@ -456,11 +458,18 @@ def test_other_transfer_pairs(ctx, oracle, src, dst):
         assert np.array_equal(got, want), (mat, np.count_nonzero(got != want))
 
 
-def test_rho_gamma_source_is_refused(ctx):
-    d = h.make_desc(64, 32, src_transfer=18, dst_transfer=8)
-    with pytest.raises(h.H2YError) as e:
-        ctx.convert_frame(d, [np.zeros(64 * 32, np.float32)] * 3)
-    assert e.value.code == 2
+def test_rho_gamma_source_out_of_range_samples(ctx, oracle):
+    """RHO_GAMMA_f on samples outside [0, 1]: negative V gives (25^V - 1) / 24 < 0 and pow(negative, 2.4) = NaN, large V
+    overflows powf to infinity: the reference's conversions of those, byte for byte."""
+    rng = np.random.default_rng(18)
+    w, hh = 64, 16
+    planes = [rng.uniform(-0.5, 1.5, w * hh).astype(np.float32) for _ in range(3)]
+    planes[0][:6] = [0.0, 1.0, -0.0, 30.0, -40.0, 1e-30]
+    for (mat, depth, chroma) in ((h.MATRIX_BT2020NC, 12, h.CHROMA_420), (h.MATRIX_YDZDX, 16, h.CHROMA_444)):
+        d = h.make_desc(w, hh, dst_depth=depth, src_transfer=18, dst_transfer=16, dst_matrix=mat, chroma=chroma, resampler=1, stats=[(0, 1)] * 3)
+        got = ctx.convert_frame(d, planes)
+        want = oracle.convert_frame(_to_oracle_desc(d), planes)
+        assert np.array_equal(got, want), (mat, int(np.count_nonzero(got != want)))
 
 
 def _picture_like(rng, w, hh):

@@ -1386,10 +1386,9 @@ int h2y_stream_submit(h2y_ctx *ctx)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t pb = h2y_plane_bytes(d), ob = h2y_frame_bytes(d);
     frame_io io;
-    for (int c = 0; c < 3; c++) {
-        io.in[c] = s.d_in + c * ctx->s_plane_al;
-        HIP_TRY(ctx, hipMemcpyAsync(s.d_in + c * ctx->s_plane_al, s.h_in + c * ctx->s_plane_al, pb, hipMemcpyHostToDevice, ctx->s_h2d));
-    }
+    for (int c = 0; c < 3; c++) io.in[c] = s.d_in + c * ctx->s_plane_al;
+    /* the slot's three planes lie one after the other (each padded to 256 bytes): one copy command, not three */
+    HIP_TRY(ctx, hipMemcpyAsync(s.d_in, s.h_in, 2 * ctx->s_plane_al + pb, hipMemcpyHostToDevice, ctx->s_h2d));
     io.out = s.d_out;
     io.tmp_cb = io.tmp_cr = nullptr;
     HIP_TRY(ctx, hipEventRecord(s.ev_h2d, ctx->s_h2d));

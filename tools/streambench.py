@@ -15,7 +15,7 @@ from hdr2yuv_amd.synth import synth_frame
 
 
 def main():
-    n = int(os.environ.get("N", "40"))
+    n = int(os.environ.get("N", "200"))  # long enough for the start-up (three slots filled by host copies) not to weigh
     depth = int(os.environ.get("DEPTH", "3"))
     w, hh = 3840, 2160
     d = h.make_desc(w, hh, dst_depth=12, dst_matrix=9, resampler=0)

@@ -504,6 +504,7 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
             fa.total_units = (uint32_t)units;
             fa.table = ctx->d_table;
             fa.table1 = ctx->d_table1;
+            fa.lut16 = ctx->d_lut16;
             fa.sn = sn;
             fa.partial = ctx->b->d_partial;
             fa.redo_count = ctx->b->d_redo;
@@ -517,11 +518,11 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
                 HIP_TRY(ctx, hipEventRecord(ctx->b->ev[ctx->b->n_ev][0], ctx->stream));
                 ctx->last_name = "k_fir_fused";
                 char buf[192];
-                snprintf(buf, sizeof buf, "k_fir_fused<%s,420FIR,%s,%s> strips=%u segments=%u rows=%u", var.in_kind == H2Y_IN_F16 ? "F16" : "F32",
-                         var.mode == H2Y_MODE_YCBCR ? "YCBCR" : "YDZDX", ident ? "PQ_IDENT" : "PQ_NORM", ns, nseg, seg_rows);
+                snprintf(buf, sizeof buf, "k_fir_fused<%s,420FIR,%s,%s%s> strips=%u segments=%u rows=%u", var.in_kind == H2Y_IN_F16 ? "F16" : "F32",
+                         var.mode == H2Y_MODE_YCBCR ? "YCBCR" : "YDZDX", ident ? "PQ_IDENT" : "PQ_NORM", var.pipe == 3 ? ",LUT16" : "", ns, nseg, seg_rows);
                 ctx->last_variant = buf;
             }
-            HIP_TRY(ctx, h2y_launch_fir_fused(var.in_kind, var.mode, ident, grid, ctx->stream, fa));
+            HIP_TRY(ctx, h2y_launch_fir_fused(var.in_kind, var.mode, ident, var.pipe == 3 /* the 16 384-entry table applies */, grid, ctx->stream, fa));
             if (ev) {
                 HIP_TRY(ctx, hipEventRecord(ctx->b->ev[ctx->b->n_ev][1], ctx->stream));
                 ctx->b->n_ev++;

@@ -126,16 +126,27 @@ struct ff_hist {
     }
 };
 
-template <int IN_KIND, int MODE, int PIPE>
+/* TIER: how a sample's PQ value is found.
+ *   FF_TIER_T1     float or half input: binary32 first tier, binary64 tier for the pixel positions it cannot settle
+ *   FF_TIER_LUT16  half input with floor 0 / ceiling 1: the table of all 16 384 halves in [0, 2) (k_fused_lut16's, exact
+ *                  by construction); a pixel with a sample outside it, or whose division guard fires, takes the careful tier */
+#define FF_TIER_T1 0
+#define FF_TIER_LUT16 1
+__device__ __forceinline__ uint32_t half_bits_of(float v) { return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)v); } /* exact: v was a half */
+
+template <int IN_KIND, int MODE, int PIPE, int TIER>
 __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
 {
-    __shared__ pq_rec1 s_t1[H2Y_T1_NREC];
-    __shared__ pq_recA s_t2[2 * H2Y_PQ_NREC]; /* A records, then B records */
+    __shared__ pq_rec1 s_t1[TIER == FF_TIER_T1 ? H2Y_T1_NREC : 1];
+    __shared__ pq_recA s_t2[TIER == FF_TIER_T1 ? 2 * H2Y_PQ_NREC : 1]; /* A records, then B records */
+    __shared__ float s_lut[TIER == FF_TIER_LUT16 ? H2Y_LUT16_N : 1];
     __shared__ pix_params s_pp;
     const pq_recA *sA = s_t2;
-    const pq_recB *sB = reinterpret_cast<const pq_recB *>(s_t2 + H2Y_PQ_NREC);
-    stage16<FF_THREADS, H2Y_T1_NREC>(a.table1, s_t1);
-    stage_table<FF_THREADS>(a.table, s_t2);
+    const pq_recB *sB = reinterpret_cast<const pq_recB *>(s_t2 + (TIER == FF_TIER_T1 ? H2Y_PQ_NREC : 0));
+    if (TIER == FF_TIER_T1) {
+        stage16<FF_THREADS, H2Y_T1_NREC>(a.table1, s_t1);
+        stage_table<FF_THREADS>(a.table, s_t2);
+    } else stage16<FF_THREADS, H2Y_LUT16_N / 4>(a.lut16, s_lut);
     const pix_params pp = with_assumed(a.pp, a.assumed);
     t1_sens sn = a.sn;
     asm volatile("" : "+v"(sn.a_lo), "+v"(sn.a_hi));
@@ -207,6 +218,25 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
                 uint32_t Y[4], Cb[4], Cr[4];
 #pragma unroll
                 for (int col = 0; col < 4; col++) {
+                    if (TIER == FF_TIER_LUT16) {
+                        const uint32_t hg = half_bits_of(gv[col]), hb = half_bits_of(bv[col]), hr = half_bits_of(rv[col]);
+                        const float lg = s_lut[hg & (H2Y_LUT16_N - 1)], lb = s_lut[hb & (H2Y_LUT16_N - 1)], lr = s_lut[hr & (H2Y_LUT16_N - 1)];
+                        __builtin_amdgcn_sched_barrier(0);
+                        const float g = pix_scale(lg, pp.mulY, pp.addY), b = pix_scale(lb, pp.mulC, pp.addC), rr = pix_scale(lr, pp.mulC, pp.addC);
+                        bool um;
+                        pix_matrix<MODE, false>(pp, g, b, rr, Y[col], Cb[col], Cr[col], &um);
+                        const bool fl = (((hg | hb | hr) & ~(uint32_t)(H2Y_LUT16_N - 1)) != 0) | um; /* negative, >= 2.0, inf, NaN; or the division guard */
+                        const uint64_t fm = __builtin_amdgcn_ballot_w64(fl);
+                        if (__builtin_expect(fm != 0, 0)) {
+                            if (fl) {
+                                const ycc k = pixel_careful<MODE>(&s_pp, gv[col], bv[col], rv[col]);
+                                Y[col] = k.y; Cb[col] = k.cb; Cr[col] = k.cr;
+                            }
+                            flagged += (uint32_t)__popcll(fm);
+                            low_m |= __builtin_amdgcn_ballot_w64(fl && min3f(gv[col], bv[col], rv[col]) <= -1.0f);
+                        }
+                        continue;
+                    }
                     const float Gn = norm1<PIPE>(pp, 0, gv[col]), Bn = norm1<PIPE>(pp, 1, bv[col]), Rn = norm1<PIPE>(pp, 2, rv[col]);
                     const pq_rec1 cg = pq_t1_fetch(Gn, s_t1), cb = pq_t1_fetch(Bn, s_t1), cr = pq_t1_fetch(Rn, s_t1);
                     __builtin_amdgcn_sched_barrier(0);
@@ -305,14 +335,20 @@ typedef void (*firf_fn)(firf_args);
 template <int IN_KIND> static firf_fn pick_firf(int mode, int pipe)
 {
     if (mode == H2Y_MODE_YCBCR)
-        return pipe == H2Y_PIPE_PQ_IDENT ? k_fir_fused<IN_KIND, H2Y_MODE_YCBCR, H2Y_PIPE_PQ_IDENT> : k_fir_fused<IN_KIND, H2Y_MODE_YCBCR, H2Y_PIPE_PQ_NORM>;
-    return pipe == H2Y_PIPE_PQ_IDENT ? k_fir_fused<IN_KIND, H2Y_MODE_YDZDX, H2Y_PIPE_PQ_IDENT> : k_fir_fused<IN_KIND, H2Y_MODE_YDZDX, H2Y_PIPE_PQ_NORM>;
+        return pipe == H2Y_PIPE_PQ_IDENT ? k_fir_fused<IN_KIND, H2Y_MODE_YCBCR, H2Y_PIPE_PQ_IDENT, FF_TIER_T1>
+                                         : k_fir_fused<IN_KIND, H2Y_MODE_YCBCR, H2Y_PIPE_PQ_NORM, FF_TIER_T1>;
+    return pipe == H2Y_PIPE_PQ_IDENT ? k_fir_fused<IN_KIND, H2Y_MODE_YDZDX, H2Y_PIPE_PQ_IDENT, FF_TIER_T1>
+                                     : k_fir_fused<IN_KIND, H2Y_MODE_YDZDX, H2Y_PIPE_PQ_NORM, FF_TIER_T1>;
 }
 
-hipError_t h2y_launch_fir_fused(int in_kind, int mode, bool ident, int grid, hipStream_t st, const firf_args &a)
+hipError_t h2y_launch_fir_fused(int in_kind, int mode, bool ident, bool lut16, int grid, hipStream_t st, const firf_args &a)
 {
     const int pipe = ident ? H2Y_PIPE_PQ_IDENT : H2Y_PIPE_PQ_NORM;
-    firf_fn fn = in_kind == H2Y_IN_F16 ? pick_firf<H2Y_IN_F16>(mode, pipe) : pick_firf<H2Y_IN_F32>(mode, pipe);
+    firf_fn fn;
+    if (lut16) /* half input, floor 0 / ceiling 1 */
+        fn = mode == H2Y_MODE_YCBCR ? k_fir_fused<H2Y_IN_F16, H2Y_MODE_YCBCR, H2Y_PIPE_PQ_IDENT, FF_TIER_LUT16>
+                                    : k_fir_fused<H2Y_IN_F16, H2Y_MODE_YDZDX, H2Y_PIPE_PQ_IDENT, FF_TIER_LUT16>;
+    else fn = in_kind == H2Y_IN_F16 ? pick_firf<H2Y_IN_F16>(mode, pipe) : pick_firf<H2Y_IN_F32>(mode, pipe);
     hipLaunchKernelGGL(fn, dim3(grid), dim3(FF_THREADS), 0, st, a);
     return hipGetLastError();
 }

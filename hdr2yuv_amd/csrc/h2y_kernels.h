@@ -143,6 +143,7 @@ struct firf_args {
     uint32_t units_per_frame; /* n_seg * n_strips */
     uint32_t total_units;     /* n_frames * units_per_frame */
     const void *table, *table1;
+    const float *lut16;       /* FF_TIER_LUT16: PQ of every half in [0, 2) */
     h2y::t1_sens sn;
     float *partial;           /* [n_frames][units_per_frame][6] */
     uint32_t *redo_count;     /* [n_frames][units_per_frame] */
@@ -172,7 +173,7 @@ hipError_t h2y_launch_stats(int in_kind, int grid, hipStream_t st, const stats_a
 hipError_t h2y_launch_stats_final(int n_frames, hipStream_t st, const final_args &a);
 hipError_t h2y_launch_fir420(hipStream_t st, const fir_args &a);
 hipError_t h2y_launch_inverse(int grid, hipStream_t st, const inverse_args &a);
-hipError_t h2y_launch_fir_fused(int in_kind, int mode, bool ident, int grid, hipStream_t st, const firf_args &a);
+hipError_t h2y_launch_fir_fused(int in_kind, int mode, bool ident, bool lut16, int grid, hipStream_t st, const firf_args &a);
 hipError_t h2y_launch_up444(hipStream_t st, const up_args &a);
 hipError_t h2y_launch_box420(hipStream_t st, const uint16_t *src, uint16_t *dst, int W, int H);
 

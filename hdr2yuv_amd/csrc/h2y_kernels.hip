@@ -730,7 +730,11 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
                     const float(&gv)[4] = row ? v.g1 : v.g0;
                     const float(&bv)[4] = row ? v.b1 : v.b0;
                     const float(&rv)[4] = row ? v.r1 : v.r0;
-if (PIPE == H2Y_PIPE_PQ_IDENT) {
+#ifdef H2Y_EXP_NOSTATS /* timing experiment only: what do twelve vector instructions per tile cost? */
+                    if (false) {
+#else
+                    if (PIPE == H2Y_PIPE_PQ_IDENT) {
+#endif
                         /* Assumed floor 0 / ceiling 1: the maximum of every sample is needed (is there one >= 1?),
                          * of the minimum only that it lies in (-1, 1).  In-table samples are positive; a sample
                          * <= -1 is out of the table, so its tile meets redo_pass(), which reports it.  That leaves
@@ -741,9 +745,11 @@ if (PIPE == H2Y_PIPE_PQ_IDENT) {
                         else { mm.add2_max(0, gv[0], gv[1]); mm.add2_max(1, bv[0], bv[1]); mm.add2_max(2, rv[0], rv[1]); }
                         mm.add2_max(0, gv[2], gv[3]); mm.add2_max(1, bv[2], bv[3]); mm.add2_max(2, rv[2], rv[3]);
                     } else {
+#ifndef H2Y_EXP_NOSTATS
                         mm.add2(0, gv[0], gv[1]); mm.add2(0, gv[2], gv[3]);
                         mm.add2(1, bv[0], bv[1]); mm.add2(1, bv[2], bv[3]);
                         mm.add2(2, rv[0], rv[1]); mm.add2(2, rv[2], rv[3]);
+#endif
                     }
                     uint32_t Y[4], Cb[4], Cr[4];
 #ifndef H2Y_T1_AHEAD

@@ -652,7 +652,10 @@ H2Y_FN pq_rec1 pq_t1_fetch(float x, const pq_rec1 *__restrict__ T)
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef const __attribute__((address_space(3))) pq_rec1 *lds_rec;
     const uint32_t tbase = (uint32_t)(uintptr_t)(lds_rec)T - ((H2Y_T1_BASE - 1u) << 4);
-    const uint32_t seg = f2bits(__builtin_amdgcn_fmed3f(x, bits2f(H2Y_T1_LO_SENTINEL_BITS), 2.0f)) >> H2Y_T1_LOW_BITS;
+    uint32_t seg = f2bits(__builtin_amdgcn_fmed3f(x, bits2f(H2Y_T1_LO_SENTINEL_BITS), 2.0f)) >> H2Y_T1_LOW_BITS;
+#ifdef H2Y_EXP_NOCONFLICT /* timing experiment only (wrong records): what would conflict-free table reads buy? */
+    seg = (seg & ~15u) | (__builtin_amdgcn_mbcnt_lo(~0u, 0u) & 15u);
+#endif
     uint32_t addr;
     asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(addr) : "v"(seg), "s"(tbase));
     return *(lds_rec)(uintptr_t)addr;

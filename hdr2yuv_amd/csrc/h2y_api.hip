@@ -111,6 +111,7 @@ struct h2y_ctx {
     bool fir_used[2] = {false, false};
     void *d_table = nullptr;
     void *d_table1 = nullptr; /* binary32 first-tier records */
+    void *d_tfn[H2Y_TFN_COUNT] = {}; /* the other transfer functions' tables (tfn_build_table), built when first needed */
     float *d_lut16 = nullptr; /* PQ10000_r of every half in [0,2), built on the device at creation */
     /* The first tier is slow on pictures with many exactly-zero samples (black bars: every such tile is done twice).
      * The kernel counts the tiles it had to redo; when their share in a batch exceeds kT1DenseShare the next
@@ -238,6 +239,8 @@ void derive_params(const h2y_desc *d, pix_params *pp, bool stage_matrix_only)
     pp->dst_tf = tf_class(d->dst_transfer);
     if (d->src_transfer == d->dst_transfer) pp->convert_transfer = 0; /* convert.cpp:930 */
     else pp->convert_transfer = (pp->src_tf == H2Y_TF_LINEAR && pp->dst_tf == H2Y_TF_PQ) ? 1 : 2;
+    /* the two stages of a generic pair (tables in h2y_math.h); -1 until run_frames() has the tables on the device */
+    pp->src_fn = pp->dst_fn = -1;
     /* convert.cpp:1123-1145 (full range: multiply only; add stays 0.0f) */
     if (d->dst_full_range) {
         pp->mulY = pp->mulC = (float)tc.maxCV;
@@ -427,6 +430,21 @@ void balance_update(h2y_ctx *ctx)
     ctx->bal_mask = m;
     ctx->bal_rho = (sf / nf) / (ss / (8 - nf));
     if (ctx->bal_rho > 1.5) ctx->bal_rho = 1.5;
+}
+
+/* the table of transfer function fn on the device (built on the host the first time it is asked for) */
+int ensure_tfn(h2y_ctx *ctx, int fn)
+{
+    if (fn <= H2Y_TFN_NONE || fn >= H2Y_TFN_COUNT || ctx->d_tfn[fn]) return 0;
+    std::vector<pq_recA> A(H2Y_PQ_NREC);
+    std::vector<pq_recB> B(H2Y_PQ_NREC);
+    (void)tfn_build_table(fn, A.data(), B.data());
+    char *t = nullptr;
+    HIP_TRY(ctx, hipMalloc((void **)&t, H2Y_PQ_TABLE_BYTES));
+    ctx->d_tfn[fn] = t;
+    HIP_TRY(ctx, hipMemcpy(t, A.data(), H2Y_PQ_NREC * 16, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(t + H2Y_PQ_NREC * 16, B.data(), H2Y_PQ_NREC * 16, hipMemcpyHostToDevice));
+    return 0;
 }
 
 /* launch fused (+FIR) over frames [0,n) whose frame_io entries are in h_frames */
@@ -638,12 +656,26 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         a.chunks_per_frame = g.chunks;
         a.groups = (uint32_t)groups;
         a.table = ctx->d_table;
+        a.table_src = a.table_dst = nullptr;
         a.lut16 = ctx->d_lut16;
         a.table1 = ctx->d_table1;
         a.sn = sn;
         a.partial = ctx->b->d_partial;
         a.assumed = d_assumed;
         a.pp = pp;
+        if (pp.convert_transfer == 2 && !var.narrow && var.pipe == 0) {
+            /* generic transfer pair through the table tier: source function, then destination function */
+            static const int kSrcFn[4] = {H2Y_TFN_NONE, H2Y_TFN_PQ_F, H2Y_TFN_RHO_H, H2Y_TFN_G24};    /* by H2Y_TF_* class */
+            static const int kDstFn[4] = {H2Y_TFN_NONE, H2Y_TFN_PQ_R, H2Y_TFN_RHO_R, H2Y_TFN_G24INV};
+            const int sf = kSrcFn[pp.src_tf], df = kDstFn[pp.dst_tf];
+            int rc2 = ensure_tfn(ctx, sf);
+            if (!rc2) rc2 = ensure_tfn(ctx, df);
+            if (rc2) return rc2;
+            a.pp.src_fn = sf;
+            a.pp.dst_fn = df;
+            a.table_src = sf ? ctx->d_tfn[sf] : nullptr;
+            a.table_dst = df ? ctx->d_tfn[df] : nullptr;
+        }
         a.tiles_magic = g.tiles > 1 ? (uint32_t)(0x100000000ull / g.tiles) : 0xFFFFFFFFu;
         const bool ev = time_it && ctx->b->n_ev < kMaxEvents;
         if (ev) {
@@ -968,6 +1000,7 @@ void h2y_ctx_destroy(h2y_ctx *ctx)
         (void)hipHostFree(b.h_assumed);
     }
     (void)hipFree(ctx->d_table);
+    for (void *t : ctx->d_tfn) (void)hipFree(t);
     (void)hipFree(ctx->d_lut16);
     (void)hipFree(ctx->d_table1);
     (void)hipFree(ctx->d_tmp);
@@ -1542,6 +1575,7 @@ int h2y_matrix_convert(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3
     a.chunks_a = g.chunks;
     a.block_clock = nullptr;
     a.table = ctx->d_table;
+    a.table_src = a.table_dst = nullptr; /* (a generic transfer pair takes the careful tier in this stage entry) */
     a.lut16 = ctx->d_lut16;
     a.table1 = ctx->d_table1;
     memset(&a.sn, 0, sizeof a.sn);

@@ -268,10 +268,31 @@ __device__ __forceinline__ bool pixel_fast(const pix_params &pp, const pq_recA *
     float g = G, b = B, r = R;
     bool unsure = false;
     if (PIPE == H2Y_PIPE_RUNTIME && pp.convert_transfer == 2) {
-        Y = Cb = Cr = 0;
-        return true; /* no fast tier for this transfer pair */
-    }
-    if (conv) {
+        /* any other transfer pair (convert.cpp:1024-1109): source function -> linear light (a float, as in the reference)
+         * -> destination function, each through its own table (tfn_fast, h2y_math.h): the source's in the first table
+         * slot of the block's LDS image, the destination's in the second */
+        if (pp.src_fn < 0) {
+            Y = Cb = Cr = 0;
+            return true; /* no tables for this launch: careful tier */
+        }
+        const pq_recA *t_src = sA, *t_dst = sA + 2 * H2Y_PQ_NREC;
+        float v[3] = {G, B, R};
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            float x = v[c];
+            bool s1 = false, s2 = false;
+            if (pp.src_fn) {
+                if (pp.src_fn == H2Y_TFN_RHO_H) x = (powf25(x) - 1.0f) * 0.0625f; /* RHO_GAMMA_f's inner powf, then (P - 1) / 16: both exact */
+                x = tfn_fast(x, t_src, tfn_cut_of(pp.src_fn), tfn_zero_bits(pp.src_fn), tfn_one_bits(pp.src_fn), &s1);
+            }
+            if (pp.dst_fn) x = tfn_fast(x, t_dst, tfn_cut_of(pp.dst_fn), tfn_zero_bits(pp.dst_fn), tfn_one_bits(pp.dst_fn), &s2);
+            unsure |= s1 | s2;
+            v[c] = x;
+        }
+        g = pix_scale(v[0], pp.mulY, pp.addY);
+        b = pix_scale(v[1], pp.mulC, pp.addC);
+        r = pix_scale(v[2], pp.mulC, pp.addC);
+    } else if (conv) {
         bool sg, sb, sr;
         g = pix_scale(pq_fast(G, sA, sB, &sg), pp.mulY, pp.addY);
         b = pix_scale(pq_fast(B, sA, sB, &sb), pp.mulC, pp.addC);

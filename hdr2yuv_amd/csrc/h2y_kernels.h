@@ -66,6 +66,8 @@ struct fused_args {
     uint32_t chunks_a;        /* xcd_layout: chunks [0, chunks_a) of a frame go round all blocks, the rest round the fast ones */
     unsigned long long *block_clock; /* [gridDim.x][2]: start, finish (wall_clock64) of each block, or NULL; finish entries zero at launch */
     const void *table;        /* pq_recA[NREC] then pq_recB[NREC] */
+    const void *table_src, *table_dst; /* k_fused, generic transfer pair (pp.convert_transfer == 2): the two stages' tables in the same
+                                          format (tfn_build_table), or NULL for a stage that is the identity */
     const float *lut16;       /* k_fused_lut16: PQ of every half in [0,2) */
     const void *table1;       /* k_fused_t1: pq_rec1[H2Y_T1_NREC] */
     h2y::t1_sens sn;          /* k_fused_t1: sensitivity windows */

@@ -255,13 +255,18 @@ __device__ __forceinline__ void tile_exact(const pix_params &pp, const pix_param
  * MODE: H2Y_MODE_YCBCR / H2Y_MODE_YDZDX compiled in, or H2Y_MODE_RUNTIME.
  */
 template <int IN_KIND, int OUT_KIND, int MODE, int PIPE>
-__global__ __launch_bounds__(H2Y_FUSED_THREADS, H2Y_FUSED_MINWAVES) void k_fused(fused_args a)
+__global__ __launch_bounds__(H2Y_FUSED_THREADS, PIPE == H2Y_PIPE_RUNTIME ? 2 : H2Y_FUSED_MINWAVES) void k_fused(fused_args a) /* (the runtime form holds two tables: one block of 512 per CU) */
 {
-    __shared__ pq_recA s_tab[2 * H2Y_PQ_NREC]; /* A records, then B records */
+    /* A records, then B records; the runtime form has room for a second table (the two stages of a generic transfer pair) */
+    __shared__ pq_recA s_tab[(PIPE == H2Y_PIPE_RUNTIME ? 4 : 2) * H2Y_PQ_NREC];
     const pq_recA *sA = s_tab;
     const pq_recB *sB = reinterpret_cast<const pq_recB *>(s_tab + H2Y_PQ_NREC);
     __shared__ pix_params s_pp;
     if (PIPE != H2Y_PIPE_RUNTIME || a.pp.convert_transfer == 1) stage_table<H2Y_FUSED_THREADS>(a.table, s_tab);
+    if (PIPE == H2Y_PIPE_RUNTIME && a.pp.convert_transfer == 2) {
+        if (a.table_src) stage_table<H2Y_FUSED_THREADS>(a.table_src, s_tab);
+        if (a.table_dst) stage_table<H2Y_FUSED_THREADS>(a.table_dst, s_tab + 2 * H2Y_PQ_NREC);
+    }
     const pix_params pp = with_assumed(a.pp, a.assumed);
     if (threadIdx.x == 0) s_pp = pp;
     __syncthreads();

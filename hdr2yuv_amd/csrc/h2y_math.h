@@ -32,6 +32,7 @@
 #define H2Y_MATH_H
 
 #include <stdint.h>
+#include <vector>
 
 #if defined(__HIPCC__)
 #define H2Y_FN __host__ __device__ __forceinline__
@@ -587,6 +588,185 @@ inline void pq_build_table(pq_recA *A, pq_recB *B)
 }
 
 /* ------------------------------------------------------------------------
+ * The same tier for the OTHER transfer functions of the dispatch point (convert.cpp:12-87, :1024-1109):
+ * every one of them is (float)F(double(x)) for a smooth F, so the table machinery of PQ10000_r carries over -- a
+ * degree-4 polynomial per (exponent, top-6-mantissa-bits) segment of x in [2^-24, 2), binary64 evaluation, result
+ * trusted only when its rounding to float is not within H2Y_PQ_AMBIG_ULPS of a tie.  What differs per function:
+ *   - the reference function in double-double (tfn_exact_dd) the table is fitted to;
+ *   - segments the polynomial cannot be trusted on are found by MEASURING it against that reference at 33 points
+ *     per segment at build time; they, and their neighbours, get the sentinel record (value on a rounding tie => the
+ *     sample goes to the careful tier): the kink of PQ10000_f where its numerator crosses zero, the foot of
+ *     RHO_GAMMA_f at P = 1, anything that is NaN or would round to a subnormal float;
+ *   - the value at +0.0 (outside the table): 0 for all of them.
+ * A transfer pair is two stages with a float in between, as in the reference: source function -> linear light
+ * (float) -> destination function.  RHO_GAMMA_f = H(powf25(V)) with H(P) = ((P - 1) / 24)^2.4: powf25() is exact by
+ * construction, H is tabulated over P / 16 (P in [1, 25] -> [1/16, 25/16), inside the table's domain).
+ * tools/pq_check tfx compares every function's fast tier with libm over every float of the table's domain.
+ * ---------------------------------------------------------------------- */
+enum : int { H2Y_TFN_NONE = 0, H2Y_TFN_PQ_R = 1, H2Y_TFN_PQ_F = 2, H2Y_TFN_G24 = 3, H2Y_TFN_G24INV = 4, H2Y_TFN_RHO_R = 5, H2Y_TFN_RHO_H = 6, H2Y_TFN_COUNT = 7 };
+#define H2Y_GAMMA24 ((double)2.4f)       /* "const float gamma = 2.4" promoted (convert.cpp:15, :1052) */
+#define H2Y_LOGF25 ((double)bits2f(0x404E0210u)) /* logf(25.0f), convert.cpp:35 */
+
+/* How a function's table cuts the floats into segments: 2^seg_bits segments per binade over the binades emin .. 0
+ * ((1 - emin) << seg_bits segments, at most H2Y_PQ_NSEG; the sentinel is record H2Y_PQ_NSEG as ever).  Most functions
+ * take PQ10000_r's cut (64 per binade from 2^-24).  PQ10000_f is steep where it matters -- locally V^10 near V = 1,
+ * with a pole at V = 1.99 -- and needs 256 segments per binade for the degree-4 fit to reach 2^-43; its table covers
+ * [2^-5, 2) = six binades (PQ code values below 0.03: the careful tier; exact zero has its own answer). */
+struct tfn_cut {
+    int seg_bits, emin;
+};
+H2Y_FN tfn_cut tfn_cut_of(int fn)
+{
+    return fn == H2Y_TFN_PQ_F ? tfn_cut{8, -5} : tfn_cut{H2Y_PQ_SEG_BITS, H2Y_PQ_EMIN};
+}
+H2Y_FN int tfn_nseg(tfn_cut c) { return (1 - c.emin) << c.seg_bits; }
+
+H2Y_FN dd dd_log_dd(dd x) { return dd_add_d(dd_log(x.hi), x.lo / x.hi); } /* log(hi + lo) = log hi + log1p(lo / hi) */
+H2Y_FN dd dd_pow_d(dd x, double e) { return dd_exp_dd(dd_mul_d(dd_log_dd(x), e)); }
+H2Y_FN dd dd_nan(void) { return {bits2d(0x7FF8000000000000ull), 0.0}; }
+/* F(x) for x > 0 (a double-double); NaN where the reference's function is NaN or the table must not be used */
+H2Y_FN dd tfn_exact_dd(int fn, dd x)
+{
+    switch (fn) {
+    case H2Y_TFN_PQ_R: return pq_exact_dd(x);
+    case H2Y_TFN_PQ_F: { /* convert.cpp:49 */
+        const dd p = dd_pow_d(x, 1.0 / 78.84375);
+        const dd num = dd_add_d(p, -0.8359375);
+        if (!(num.hi > 0.0)) return {0.0, 0.0}; /* fmax(., 0.0), then pow(0, 1/m1) = 0 */
+        /* Above V = 1 the segments are twice as wide and the function heads for its pole at V = 1.99, where the
+         * reference's own double arithmetic (c2 - c3 p, with p rounded) loses digits too: no table there.  V = 1.0
+         * itself -- peak white -- has its own answer (tfn_one_bits). */
+        if (x.hi >= 1.0) return dd_nan();
+        const dd den = dd_add_d(dd_mul_d(p, -18.6875), 18.8515625);
+        return dd_pow_d(dd_div(num, den), 1.0 / 0.1593017578);
+    }
+    case H2Y_TFN_G24: return dd_pow_d(x, H2Y_GAMMA24);          /* bt1886_f with a = 1, b = 0, convert.cpp:73 */
+    case H2Y_TFN_G24INV: return dd_pow_d(x, 1. / H2Y_GAMMA24);  /* bt1886_r, convert.cpp:85 */
+    case H2Y_TFN_RHO_R: { /* convert.cpp:35 */
+        const dd t = dd_pow_d(x, 1.0 / H2Y_GAMMA24);
+        const dd a = dd_add_d(dd_mul_d(t, 24.0), 1.0);
+        return dd_div(dd_log_dd(a), dd{H2Y_LOGF25, 0.0});
+    }
+    case H2Y_TFN_RHO_H: /* convert.cpp:23 after the inner powf: x = (P - 1) / 16 (exact in binary32 for P in [1, 2^24)),
+                           H = ((P - 1) / 24)^2.4 = (x / 1.5)^2.4 -- a pure power of x: every binade looks the same */
+        return dd_pow_d(dd_div(x, dd{1.5, 0.0}), H2Y_GAMMA24);
+    default: return dd_nan();
+    }
+}
+/* float value of the function at +0.0 (bits) */
+H2Y_FN uint32_t tfn_zero_bits(int fn) { return fn == H2Y_TFN_PQ_R ? H2Y_PQ_AT_ZERO_BITS : 0u; }
+/* float value at 1.0f where that input has an answer of its own (PQ10000_f(1) = 1: p = 1, (1 - c1) / (c2 - c3) = 1), else 0 = none */
+H2Y_FN uint32_t tfn_one_bits(int fn) { return fn == H2Y_TFN_PQ_F ? 0x3F800000u : 0u; }
+
+/* the polynomial of one segment: pq_poly() with the cut as a parameter */
+H2Y_FN double tfn_poly(uint32_t bits, int seg_bits, const pq_recA &a, const pq_recB &b)
+{
+    const int low_bits = 23 - seg_bits;
+    const float f = bits2f((bits & ((1u << low_bits) - 1u)) | 0x3F800000u);
+    const float u = f - bits2f(0x3F800000u + (1u << (low_bits - 1))); /* minus the segment centre 1 + 2^-(seg_bits + 1): exact */
+    const float p = __builtin_fmaf(b.c4, u, b.c3);
+    const double ud = (double)u;
+    double v = __builtin_fma((double)p, ud, b.c2);
+    v = __builtin_fma(v, ud, a.c1);
+    return __builtin_fma(v, ud, a.c0);
+}
+/* record index; everything outside the table (0, tiny, >= 2, negative, NaN) wraps above it and lands on the sentinel */
+H2Y_FN uint32_t tfn_index(uint32_t bits, tfn_cut c)
+{
+    const int low_bits = 23 - c.seg_bits;
+    const uint32_t t = bits - ((uint32_t)(127 + c.emin) << 23);
+    return umin32(t >> low_bits, (uint32_t)H2Y_PQ_NSEG);
+}
+
+/* Generic form of pq_build_table() with the per-segment check described above.  Returns how many segments of the
+ * table's domain ended up on the sentinel.  Records beyond the cut's last segment are sentinels too. */
+inline int tfn_build_table(int fn, pq_recA *A, pq_recB *B)
+{
+    const double un[5] = {-0.9510565162951535, -0.5877852522924731, 0.0, 0.5877852522924731, 0.9510565162951535};
+    const tfn_cut cut = tfn_cut_of(fn);
+    const int nseg = tfn_nseg(cut), per = 1 << cut.seg_bits, low_bits = 23 - cut.seg_bits;
+    std::vector<unsigned char> bad(nseg, 0); /* 1: not accurate enough or not defined here; 2: a kink (takes its neighbours along) */
+    for (int i = 0; i < nseg; i++) {
+        const int e = cut.emin + i / per, sg = i % per;
+        const double scale = bits2d((uint64_t)(1023 + e) << 52);
+        const double mid = scale * (1.0 + (sg + 0.5) / per), half = scale * (0.5 / per);
+        dd dv[5];
+        bool ok = true, kink = false;
+        int zeros = 0;
+        for (int j = 0; j < 5; j++) {
+            dv[j] = tfn_exact_dd(fn, dd_add_d(two_prod(un[j], half), mid));
+            ok = ok && dv[j].hi == dv[j].hi;
+            zeros += dv[j].hi == 0.0;
+        }
+        kink = zeros != 0 && zeros != 5; /* the function leaves zero inside this segment */
+        if (ok) {
+            for (int lvl = 1; lvl < 5; lvl++)
+                for (int j = 4; j >= lvl; j--) dv[j] = dd_div(dd_add(dv[j], dd{-dv[j - 1].hi, -dv[j - 1].lo}), dd{un[j] - un[j - lvl], 0.0});
+            dd c[5] = {dv[4], {0, 0}, {0, 0}, {0, 0}, {0, 0}};
+            int deg = 0;
+            for (int j = 3; j >= 0; j--) {
+                dd nc[5] = {{0, 0}, {0, 0}, {0, 0}, {0, 0}, {0, 0}};
+                for (int k = 0; k <= deg; k++) {
+                    nc[k + 1] = dd_add(nc[k + 1], c[k]);
+                    nc[k] = dd_add(nc[k], dd_mul_d(c[k], -un[j]));
+                }
+                nc[0] = dd_add(nc[0], dv[j]);
+                deg++;
+                for (int k = 0; k <= deg; k++) c[k] = nc[k];
+            }
+            const double r = (double)(2 << cut.seg_bits);
+            A[i].c0 = c[0].hi;
+            A[i].c1 = c[1].hi * r;
+            B[i].c2 = c[2].hi * r * r;
+            B[i].c3 = (float)(c[3].hi * r * r * r);
+            B[i].c4 = (float)(c[4].hi * r * r * r * r);
+            /* measure: the polynomial as the kernels evaluate it against the reference, 33 floats across the segment */
+            const uint32_t seg_bits0 = ((uint32_t)(127 + cut.emin) << 23) + ((uint32_t)i << low_bits);
+            for (int k = 0; k <= 32 && ok; k++) {
+                const uint32_t low = k == 32 ? (1u << low_bits) - 1u : (uint32_t)k << (low_bits - 5);
+                const uint32_t bits = seg_bits0 | low;
+                const double v = tfn_poly(bits, cut.seg_bits, A[i], B[i]);
+                const dd ref = tfn_exact_dd(fn, dd{(double)bits2f(bits), 0.0});
+                if (!(ref.hi == ref.hi) || !(v == v)) { ok = false; break; }
+                const double err = (v - ref.hi) - ref.lo, mag = ref.hi < 0 ? -ref.hi : ref.hi;
+                const double aerr = err < 0 ? -err : err;
+                if (mag == 0.0) ok = aerr == 0.0;
+                else {
+                    if (mag < 0x1p-120) kink = true; /* next to where it leaves zero: relative accuracy means nothing yet */
+                    ok = mag >= 0x1p-120 && aerr <= mag * 0x1p-43; /* a quarter of the ambiguity margin (2^-41 worst case) */
+                }
+            }
+        }
+        bad[i] = kink ? 2 : (ok ? 0 : 1);
+    }
+    int nbad = 0;
+    for (int i = 0; i <= H2Y_PQ_NSEG; i++) {
+        bool b = i >= nseg || bad[i]; /* a kink takes its two neighbours on either side with it */
+        for (int k = -2; k <= 2 && !b; k++) b = i + k >= 0 && i + k < nseg && bad[i + k] == 2;
+        if (b) {
+            A[i].c0 = 1.0 + 0x1p-24; /* exactly half way between two floats: always "ambiguous" */
+            A[i].c1 = 0.0;
+            B[i].c2 = 0.0;
+            B[i].c3 = B[i].c4 = 0.0f;
+            if (i < nseg) nbad++;
+        }
+    }
+    return nbad;
+}
+/* one stage through its table (A, then B = A + H2Y_PQ_NREC records): pq_fast() with the function's own cut and value
+ * at +0.0 */
+H2Y_FN float tfn_fast(float x, const pq_recA *__restrict__ A, tfn_cut cut, uint32_t zero_bits, uint32_t one_bits, bool *slow)
+{
+    const uint32_t bits = f2bits(x), idx = tfn_index(bits, cut);
+    const pq_recA a = A[idx];
+    const pq_recB b = reinterpret_cast<const pq_recB *>(A + H2Y_PQ_NREC)[idx];
+    const double v = tfn_poly(bits, cut.seg_bits, a, b);
+    const bool zero = bits == 0u, one = one_bits != 0u && bits == 0x3F800000u;
+    *slow = pq_ambiguous(v) & !(zero | one);
+    return zero ? bits2f(zero_bits) : one ? bits2f(one_bits) : (float)v;
+}
+
+/* ------------------------------------------------------------------------
  * First tier ("T1"): binary32 only, one 16-byte record per sample.
  *
  * value = c0h + w,  w = c0l + u (c1 + u c2)   (all binary32; u exact)
@@ -755,6 +935,8 @@ struct pix_params {
     int convert_transfer;      /* convert.cpp:930.  0: transfers equal; 1: LINEAR -> PQ (fast tier available);
                                   2: any other pair the reference has code for (careful tier only) */
     int src_tf, dst_tf;        /* H2Y_TF_* classes of the two transfers */
+    int src_fn, dst_fn;        /* convert_transfer == 2: H2Y_TFN_* of the two stages' tables in LDS (source table first), 0 = no such stage,
+                                  -1 = no fast tier for this pair (careful tier for every sample) */
     int norm_identity;         /* offset 0 and range 1 for all three planes */
     float offset[3], range[3]; /* convert.cpp:939-940 */
     float mulY, addY, mulC, addC; /* scale step convert.cpp:1123-1145; G: mulY/addY, B and R: mulC/addC */

@@ -81,3 +81,19 @@ def test_powf_restatement_equals_libm_on_all_of_zero_to_one(pq_check):
                  ("0x7f800000", "0x7fc00010", "2"), ("0xff800000", "0xffc00010", "2")):
         rc, out = _run(pq_check, "powf", *args)
         assert rc == 0 and " mismatches 0" in out, out
+
+
+@pytest.mark.parametrize("fn,lo,hi,stride", [(2, "0x3d000000", "0x3f800010", 1),   # PQ10000_f on [2^-5, 1]
+                                             (3, "0x33800000", "0x40000000", 3),   # bt1886_f (x^2.4) on [2^-24, 2)
+                                             (4, "0x33800000", "0x40000000", 3),   # bt1886_r
+                                             (5, "0x33800000", "0x40000000", 3),   # RHO_GAMMA_r
+                                             (6, "0x3f800000", "0x42000000", 1)])  # RHO_GAMMA_f's outer stage over every P in [1, 32)
+def test_other_transfer_tables_equal_libm(pq_check, fn, lo, hi, stride):
+    """SURVEY 8f.2 fast tier: the table tier of every other transfer function (tfn_build_table / tfn_fast) against this
+    machine's libm over its table's domain -- whatever the tier answers (does not flag for the careful tier) must be the
+    reference's float; and it must answer nearly everything (the exhaustive stride-1 runs of functions 3-5 take 3 s more:
+    DESIGN.md)."""
+    rc, out = _run(pq_check, "tfx", str(fn), lo, hi, "8", str(stride))
+    assert rc == 0 and " mismatches 0," in out, out
+    m = re.search(r"slow tier (\d+) \(([\d.]+)%\)", out)
+    assert float(m.group(2)) < 0.01, out

@@ -127,6 +127,56 @@ int main(int argc, char **argv)
                bad[2], bad[3], bad[4]);
         return (bad[0] | bad[1] | bad[2] | bad[3] | bad[4]) ? 1 : 0; /* (RHO_f's inner powf is glibc's algorithm restated: powf25()) */
     }
+    if (!strcmp(argv[1], "tfx")) {
+        /* The table tier of the other transfer functions (tfn_build_table / tfn_fast, h2y_math.h) against this machine's
+         * libm, function by function, over every float x in [LO, HI) (bit patterns; default: the whole table domain
+         * [2^-24, 2) plus what lies around it).  A sample the tier flags "slow" is not compared (it goes to the careful
+         * tier); one it answers must be the reference's float.  pq_check tfx FN LO HI THREADS [STRIDE] */
+        const int fn = atoi(argv[2]);
+        uint32_t lo = argc > 3 ? (uint32_t)strtoul(argv[3], 0, 0) : 0x33000000u, hi = argc > 4 ? (uint32_t)strtoul(argv[4], 0, 0) : 0x40800000u;
+        int T = argc > 5 ? atoi(argv[5]) : 8;
+        uint64_t stride = argc > 6 ? strtoull(argv[6], 0, 0) : 1;
+        std::vector<pq_recA> A(2 * H2Y_PQ_NREC);
+        const int nbad = tfn_build_table(fn, A.data(), reinterpret_cast<pq_recB *>(A.data() + H2Y_PQ_NREC));
+        std::atomic<uint64_t> mism{0}, nslow{0}, total{0};
+        std::vector<std::thread> th;
+        uint64_t span = (uint64_t)hi - lo;
+        for (int t = 0; t < T; t++)
+            th.emplace_back([&, t]() {
+                uint64_t a = lo + span * t / T, b = lo + span * (t + 1) / T, mm = 0, ns = 0, n = 0;
+                for (uint64_t u = a; u < b; u += stride) {
+                    float x = bits2f((uint32_t)u);
+                    float want;
+                    if (fn == H2Y_TFN_RHO_H) { /* the stage's input is (P - 1) / 16 for a float P = powf(25, V) >= 1: walk P, not x */
+                        const float P = x;
+                        if (!(P >= 1.0f) || !(P < 16777216.0f)) continue;
+                        want = (float)pow(((double)P - 1.0) / 24.0, (double)2.4f);
+                        x = (P - 1.0f) * 0.0625f;
+                    } else
+                    switch (fn) {
+                    case H2Y_TFN_PQ_R: want = (float)pow((0.8359375 + 18.8515625 * pow((double)x, 0.1593017578)) / (1 + 18.6875 * pow((double)x, 0.1593017578)), 78.84375); break;
+                    case H2Y_TFN_PQ_F: { double p = pow((double)x, 1.0 / 78.84375); want = (float)pow(fmax(p - 0.8359375, 0.0) / (18.8515625 - 18.6875 * p), 1.0 / 0.1593017578); break; }
+                    case H2Y_TFN_G24: want = (float)(1.0 * pow(fmax((double)(x + 0.0f), 0.), (double)2.4f)); break;
+                    case H2Y_TFN_G24INV: want = (float)(pow(fmax((double)(x / 1.0f), 0.), 1. / (double)2.4f) - 0.0); break;
+                    case H2Y_TFN_RHO_R: want = (float)(log(1.0 + 24.0 * pow((double)x, 1.0 / (double)2.4f)) / (double)logf(25.0f)); break;
+                    default: want = 0.0f; break;
+                    }
+                    bool slow;
+                    const float got = tfn_fast(x, A.data(), tfn_cut_of(fn), tfn_zero_bits(fn), tfn_one_bits(fn), &slow);
+                    n++;
+                    if (slow) { ns++; continue; }
+                    if (f2bits(got) != f2bits(want) && !(got != got && want != want)) {
+                        if (mm++ < 3) fprintf(stderr, "tfx fn %d MISMATCH x=%a (0x%08x) got %a want %a\n", fn, x, (uint32_t)u, got, want);
+                    }
+                }
+                mism += mm; nslow += ns; total += n;
+            });
+        for (auto &x : th) x.join();
+        printf("tfx fn %d over [0x%08x,0x%08x) step %llu: %llu floats, mismatches %llu, slow tier %llu (%.4f%%), sentinel segments %d of %d\n", fn, lo, hi,
+               (unsigned long long)stride, (unsigned long long)total.load(), (unsigned long long)mism.load(), (unsigned long long)nslow.load(),
+               100.0 * nslow.load() / (double)total.load(), nbad, tfn_nseg(tfn_cut_of(fn)));
+        return mism ? 1 : 0;
+    }
     if (!strcmp(argv[1], "powf")) {
         /* powf25() (glibc's powf algorithm restated, h2y_math.h) against this machine's powf(25.0f, y) for every float
          * y in [LO, HI) (bit patterns); NaN results compare equal.  pq_check powf 0 0x3f800001 8 = all of [0, 1]. */

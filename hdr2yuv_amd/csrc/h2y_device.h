@@ -244,6 +244,11 @@ __device__ __attribute__((noinline)) ycc pixel_careful(const pix_params *spp /* 
     return o;
 }
 
+/* one stage of a transfer pair by the careful tier (h2y_math.h), out of line: what the table tier of the generic pairs
+ * falls back to for a single sample */
+static __device__ __attribute__((noinline)) float tf_to_linear_careful(int cls, float v) { return tf_to_linear(cls, v); }
+static __device__ __attribute__((noinline)) float tf_from_linear_careful(int cls, float v) { return tf_from_linear(cls, v); }
+
 /* PIPE: what is known at compile time about the front of the pixel pipeline */
 #define H2Y_PIPE_RUNTIME 0  /* read pp.convert_transfer / pp.norm_identity */
 #define H2Y_PIPE_PQ_IDENT 1 /* LINEAR -> PQ, floor 0 / ceiling 1: no normalisation arithmetic */
@@ -280,13 +285,19 @@ __device__ __forceinline__ bool pixel_fast(const pix_params &pp, const pq_recA *
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             float x = v[c];
-            bool s1 = false, s2 = false;
             if (pp.src_fn) {
+                bool s1;
+                const float x0 = x;
                 if (pp.src_fn == H2Y_TFN_RHO_H) x = (powf25(x) - 1.0f) * 0.0625f; /* RHO_GAMMA_f's inner powf, then (P - 1) / 16: both exact */
                 x = tfn_fast(x, t_src, tfn_cut_of(pp.src_fn), tfn_zero_bits(pp.src_fn), tfn_one_bits(pp.src_fn), &s1);
+                if (__builtin_expect(s1, 0)) x = tf_to_linear_careful(pp.src_tf, x0); /* this sample alone, not its pixel */
             }
-            if (pp.dst_fn) x = tfn_fast(x, t_dst, tfn_cut_of(pp.dst_fn), tfn_zero_bits(pp.dst_fn), tfn_one_bits(pp.dst_fn), &s2);
-            unsure |= s1 | s2;
+            if (pp.dst_fn) {
+                bool s2;
+                const float x1 = x;
+                x = tfn_fast(x, t_dst, tfn_cut_of(pp.dst_fn), tfn_zero_bits(pp.dst_fn), tfn_one_bits(pp.dst_fn), &s2);
+                if (__builtin_expect(s2, 0)) x = tf_from_linear_careful(pp.dst_tf, x1);
+            }
             v[c] = x;
         }
         g = pix_scale(v[0], pp.mulY, pp.addY);

@@ -607,19 +607,21 @@ enum : int { H2Y_TFN_NONE = 0, H2Y_TFN_PQ_R = 1, H2Y_TFN_PQ_F = 2, H2Y_TFN_G24 =
 #define H2Y_GAMMA24 ((double)2.4f)       /* "const float gamma = 2.4" promoted (convert.cpp:15, :1052) */
 #define H2Y_LOGF25 ((double)bits2f(0x404E0210u)) /* logf(25.0f), convert.cpp:35 */
 
-/* How a function's table cuts the floats into segments: 2^seg_bits segments per binade over the binades emin .. 0
- * ((1 - emin) << seg_bits segments, at most H2Y_PQ_NSEG; the sentinel is record H2Y_PQ_NSEG as ever).  Most functions
- * take PQ10000_r's cut (64 per binade from 2^-24).  PQ10000_f is steep where it matters -- locally V^10 near V = 1,
- * with a pole at V = 1.99 -- and needs 256 segments per binade for the degree-4 fit to reach 2^-43; its table covers
- * [2^-5, 2) = six binades (PQ code values below 0.03: the careful tier; exact zero has its own answer). */
+/* How a function's table cuts the floats into segments: 2^seg_bits segments per binade over the binades emin .. 0,
+ * and -- for a function that needs it -- 2^hi_seg_bits per binade from binade hi_emin up (hi_emin = 1: no such part).
+ * At most H2Y_PQ_NSEG segments in all; the records after the last are sentinels, H2Y_PQ_NSEG the catch-all one.
+ * Most functions take PQ10000_r's cut (64 per binade from 2^-24).  PQ10000_f is steep where it matters -- locally V^10
+ * near V = 1, with a pole at V = 1.99 -- and needs 256 segments per binade from 2^-3 up for the degree-4 fit to reach
+ * 2^-43; below that 64 do, down to 2^-12 (PQ code values below 0.00025: the careful tier; exact zero has its own answer). */
 struct tfn_cut {
-    int seg_bits, emin;
+    int seg_bits, emin, hi_seg_bits, hi_emin;
 };
 H2Y_FN tfn_cut tfn_cut_of(int fn)
 {
-    return fn == H2Y_TFN_PQ_F ? tfn_cut{8, -5} : tfn_cut{H2Y_PQ_SEG_BITS, H2Y_PQ_EMIN};
+    return fn == H2Y_TFN_PQ_F ? tfn_cut{6, -12, 8, -3} : tfn_cut{H2Y_PQ_SEG_BITS, H2Y_PQ_EMIN, H2Y_PQ_SEG_BITS, 1};
 }
-H2Y_FN int tfn_nseg(tfn_cut c) { return (1 - c.emin) << c.seg_bits; }
+H2Y_FN int tfn_nseg_lo(tfn_cut c) { return ((c.hi_emin < 1 ? c.hi_emin : 1) - c.emin) << c.seg_bits; }
+H2Y_FN int tfn_nseg(tfn_cut c) { return tfn_nseg_lo(c) + (c.hi_emin < 1 ? (1 - c.hi_emin) << c.hi_seg_bits : 0); }
 
 H2Y_FN dd dd_log_dd(dd x) { return dd_add_d(dd_log(x.hi), x.lo / x.hi); } /* log(hi + lo) = log hi + log1p(lo / hi) */
 H2Y_FN dd dd_pow_d(dd x, double e) { return dd_exp_dd(dd_mul_d(dd_log_dd(x), e)); }
@@ -658,7 +660,7 @@ H2Y_FN uint32_t tfn_zero_bits(int fn) { return fn == H2Y_TFN_PQ_R ? H2Y_PQ_AT_ZE
 /* float value at 1.0f where that input has an answer of its own (PQ10000_f(1) = 1: p = 1, (1 - c1) / (c2 - c3) = 1), else 0 = none */
 H2Y_FN uint32_t tfn_one_bits(int fn) { return fn == H2Y_TFN_PQ_F ? 0x3F800000u : 0u; }
 
-/* the polynomial of one segment: pq_poly() with the cut as a parameter */
+/* the polynomial of one segment: pq_poly() with the segment width as a parameter */
 H2Y_FN double tfn_poly(uint32_t bits, int seg_bits, const pq_recA &a, const pq_recB &b)
 {
     const int low_bits = 23 - seg_bits;
@@ -670,12 +672,26 @@ H2Y_FN double tfn_poly(uint32_t bits, int seg_bits, const pq_recA &a, const pq_r
     v = __builtin_fma(v, ud, a.c1);
     return __builtin_fma(v, ud, a.c0);
 }
-/* record index; everything outside the table (0, tiny, >= 2, negative, NaN) wraps above it and lands on the sentinel */
-H2Y_FN uint32_t tfn_index(uint32_t bits, tfn_cut c)
+/* record index and the segment width there; everything outside the table (0, tiny, >= 2, negative, NaN) wraps above it
+ * and lands on a sentinel */
+H2Y_FN uint32_t tfn_index(uint32_t bits, tfn_cut c, int *seg_bits)
 {
-    const int low_bits = 23 - c.seg_bits;
-    const uint32_t t = bits - ((uint32_t)(127 + c.emin) << 23);
-    return umin32(t >> low_bits, (uint32_t)H2Y_PQ_NSEG);
+    const uint32_t t_lo = bits - ((uint32_t)(127 + c.emin) << 23), t_hi = bits - ((uint32_t)(127 + c.hi_emin) << 23);
+    const bool hi = c.hi_emin < 1 && (int32_t)t_hi >= 0 && (int32_t)bits >= 0;
+    *seg_bits = hi ? c.hi_seg_bits : c.seg_bits;
+    const uint32_t i_lo = t_lo >> (23 - c.seg_bits), i_hi = (uint32_t)tfn_nseg_lo(c) + (t_hi >> (23 - c.hi_seg_bits));
+    return umin32(hi ? i_hi : i_lo, (uint32_t)H2Y_PQ_NSEG);
+}
+/* the first float of segment i, and its width */
+H2Y_FN uint32_t tfn_segment_bits(int i, tfn_cut c, int *seg_bits)
+{
+    const int n_lo = tfn_nseg_lo(c);
+    if (i < n_lo) {
+        *seg_bits = c.seg_bits;
+        return ((uint32_t)(127 + c.emin) << 23) + ((uint32_t)i << (23 - c.seg_bits));
+    }
+    *seg_bits = c.hi_seg_bits;
+    return ((uint32_t)(127 + c.hi_emin) << 23) + ((uint32_t)(i - n_lo) << (23 - c.hi_seg_bits));
 }
 
 /* Generic form of pq_build_table() with the per-segment check described above.  Returns how many segments of the
@@ -684,12 +700,14 @@ inline int tfn_build_table(int fn, pq_recA *A, pq_recB *B)
 {
     const double un[5] = {-0.9510565162951535, -0.5877852522924731, 0.0, 0.5877852522924731, 0.9510565162951535};
     const tfn_cut cut = tfn_cut_of(fn);
-    const int nseg = tfn_nseg(cut), per = 1 << cut.seg_bits, low_bits = 23 - cut.seg_bits;
+    const int nseg = tfn_nseg(cut);
     std::vector<unsigned char> bad(nseg, 0); /* 1: not accurate enough or not defined here; 2: a kink (takes its neighbours along) */
     for (int i = 0; i < nseg; i++) {
-        const int e = cut.emin + i / per, sg = i % per;
-        const double scale = bits2d((uint64_t)(1023 + e) << 52);
-        const double mid = scale * (1.0 + (sg + 0.5) / per), half = scale * (0.5 / per);
+        int sbits;
+        const uint32_t seg_bits0 = tfn_segment_bits(i, cut, &sbits);
+        const int low_bits = 23 - sbits;
+        const double x0 = (double)bits2f(seg_bits0), x1 = (double)bits2f(seg_bits0 + (1u << low_bits)); /* the segment's ends */
+        const double mid = 0.5 * (x0 + x1), half = 0.5 * (x1 - x0);
         dd dv[5];
         bool ok = true, kink = false;
         int zeros = 0;
@@ -714,18 +732,17 @@ inline int tfn_build_table(int fn, pq_recA *A, pq_recB *B)
                 deg++;
                 for (int k = 0; k <= deg; k++) c[k] = nc[k];
             }
-            const double r = (double)(2 << cut.seg_bits);
+            const double r = (double)(2 << sbits);
             A[i].c0 = c[0].hi;
             A[i].c1 = c[1].hi * r;
             B[i].c2 = c[2].hi * r * r;
             B[i].c3 = (float)(c[3].hi * r * r * r);
             B[i].c4 = (float)(c[4].hi * r * r * r * r);
             /* measure: the polynomial as the kernels evaluate it against the reference, 33 floats across the segment */
-            const uint32_t seg_bits0 = ((uint32_t)(127 + cut.emin) << 23) + ((uint32_t)i << low_bits);
             for (int k = 0; k <= 32 && ok; k++) {
                 const uint32_t low = k == 32 ? (1u << low_bits) - 1u : (uint32_t)k << (low_bits - 5);
                 const uint32_t bits = seg_bits0 | low;
-                const double v = tfn_poly(bits, cut.seg_bits, A[i], B[i]);
+                const double v = tfn_poly(bits, sbits, A[i], B[i]);
                 const dd ref = tfn_exact_dd(fn, dd{(double)bits2f(bits), 0.0});
                 if (!(ref.hi == ref.hi) || !(v == v)) { ok = false; break; }
                 const double err = (v - ref.hi) - ref.lo, mag = ref.hi < 0 ? -ref.hi : ref.hi;
@@ -757,10 +774,11 @@ inline int tfn_build_table(int fn, pq_recA *A, pq_recB *B)
  * at +0.0 */
 H2Y_FN float tfn_fast(float x, const pq_recA *__restrict__ A, tfn_cut cut, uint32_t zero_bits, uint32_t one_bits, bool *slow)
 {
-    const uint32_t bits = f2bits(x), idx = tfn_index(bits, cut);
+    int sbits;
+    const uint32_t bits = f2bits(x), idx = tfn_index(bits, cut, &sbits);
     const pq_recA a = A[idx];
     const pq_recB b = reinterpret_cast<const pq_recB *>(A + H2Y_PQ_NREC)[idx];
-    const double v = tfn_poly(bits, cut.seg_bits, a, b);
+    const double v = tfn_poly(bits, sbits, a, b);
     const bool zero = bits == 0u, one = one_bits != 0u && bits == 0x3F800000u;
     *slow = pq_ambiguous(v) & !(zero | one);
     return zero ? bits2f(zero_bits) : one ? bits2f(one_bits) : (float)v;

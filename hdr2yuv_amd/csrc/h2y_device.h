@@ -298,6 +298,7 @@ __device__ __forceinline__ bool pixel_fast(const pix_params &pp, const pq_recA *
                 x = tfn_fast(x, t_dst, tfn_cut_of(pp.dst_fn), tfn_zero_bits(pp.dst_fn), tfn_one_bits(pp.dst_fn), &s2);
                 if (__builtin_expect(s2, 0)) x = tf_from_linear_careful(pp.dst_tf, x1);
             }
+            unsure |= !(x == x); /* a NaN (negative sample through a power, ...) takes its pixel to the careful matrix: the reference's x86 conversions */
             v[c] = x;
         }
         g = pix_scale(v[0], pp.mulY, pp.addY);

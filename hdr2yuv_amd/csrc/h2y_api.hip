@@ -568,9 +568,15 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
     /* one launch covers at most kMaxFramesPerLaunch frames: k_fused_t1's waves draw their tiles from one LDS counter
      * per frame of their group (H2Y_CLAIM_FRAMES of them) */
     const int step = out_kind == H2Y_OUT_444TMP ? kFirSubBatch : (n < kMaxFramesPerLaunch ? n : kMaxFramesPerLaunch);
+    /* the 4:4:4 chroma scratch of the two-pass FIR form: as many frames as a sub-batch holds, twice over when the batch
+     * has more than one sub-batch (sub-batch i writes half i % 2 while the FIR pass still reads the other).  A single
+     * frame (h2y_convert_frame, the CLI's ring) takes 33 MB at 4K, not the 2.1 GB of a full double sub-batch. */
+    const int fir_sub = n < kFirSubBatch ? n : kFirSubBatch;
     if (out_kind == H2Y_OUT_444TMP) {
-        /* two halves: sub-batch i writes half i%2 while the FIR pass still reads the other */
-        int rc = ensure(ctx, ctx->d_tmp, ctx->tmp_cap, (size_t)2 * kFirSubBatch * 2 * npix * sizeof(uint16_t));
+        /* earlier calls may have laid their halves out differently: nothing of theirs may still be reading */
+        for (int hlf = 0; hlf < 2; hlf++)
+            if (ctx->fir_used[hlf]) HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_fir[hlf], 0));
+        int rc = ensure(ctx, ctx->d_tmp, ctx->tmp_cap, (size_t)(n > kFirSubBatch ? 2 : 1) * fir_sub * 2 * npix * sizeof(uint16_t));
         if (rc) return rc;
     }
     int sub = 0;
@@ -586,7 +592,7 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         for (int i = 0; i < nf; i++) {
             frame_io io = frames[f0 + i];
             if (out_kind == H2Y_OUT_444TMP) {
-                io.tmp_cb = ctx->d_tmp + ((size_t)half * kFirSubBatch + i) * 2 * npix;
+                io.tmp_cb = ctx->d_tmp + ((size_t)half * fir_sub + i) * 2 * npix;
                 io.tmp_cr = io.tmp_cb + npix;
             }
             const size_t idx = (size_t)ctx->slot_base + f0 + i;

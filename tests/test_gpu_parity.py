@@ -1136,3 +1136,36 @@ def test_cli_reads_raw_files(tmp_path, oracle):
     assert got[:16] == b"\x01\x02" * 8
     want = np.concatenate([oracle.convert_frame(od, yframes[k]) for k in (1, 2, 3)])
     assert np.array_equal(np.frombuffer(got[16:], np.uint16), want)
+
+
+def test_context_options_and_variant_names(oracle):
+    """h2y_ctx_set_option: every knob is per context (the library reads nothing from the environment), none changes a
+    byte; h2y_last_kernel_variant names the instantiation that ran, so a test can say which kernel it covered whatever ran
+    before it."""
+    import torch
+
+    rng = np.random.default_rng(77)
+    w, hh = 512, 128
+    host = [_rand_planes(rng, w, hh, h.SAMPLE_F32) for _ in range(8)]
+    dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in host]
+    d = h.make_desc(w, hh, dst_depth=12, dst_matrix=h.MATRIX_BT2020NC, resampler=0, stats=[(0, 1)] * 3)
+    want = [oracle.convert_frame(_to_oracle_desc(d), fr) for fr in host]
+    expect = {(): "k_fused_t1<F32,420BOX,YCBCR,PQ_IDENT> groups=8", (("t1", "0"),): "k_fused2<F32,420BOX,YCBCR,PQ_IDENT> groups=8",
+              (("groups", "2"),): "k_fused_t1<F32,420BOX,YCBCR,PQ_IDENT> groups=2", (("groups", "1"), ("balance", "off")): "k_fused_t1<F32,420BOX,YCBCR,PQ_IDENT> groups=1"}
+    for opts, name in expect.items():
+        c = h.Context(0)
+        try:
+            for k, v in opts:
+                c.set_option(k, v)
+            dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda") for _ in host]
+            torch.cuda.synchronize()
+            c.convert_batch(d, dev_in, dev_out)
+            assert c.last_kernel_variant().startswith(name), (opts, c.last_kernel_variant())
+            for f in range(len(host)):
+                assert np.array_equal(dev_out[f].cpu().numpy().view(np.uint16), want[f]), (opts, f)
+            with pytest.raises(h.H2YError):
+                c.set_option("no_such_knob", "1")
+            with pytest.raises(h.H2YError):
+                c.set_option("balance", "0xFF,1.2")  # every XCD fast is no split at all
+        finally:
+            c.close()

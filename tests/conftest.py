@@ -29,9 +29,11 @@ def ref():
     return Ref()
 
 
-@pytest.fixture(scope="session")
+@pytest.fixture()
 def ctx():
-    """Device context through the C-ABI. Fails loudly if the HIP library is missing."""
+    """A FRESH device context through the C-ABI for every test (statistics hint, tier steering and XCD balance start from
+    scratch: which kernel variant a test reaches does not depend on what ran before it).  Fails loudly if the HIP library
+    is missing."""
     import hdr2yuv_amd as h
 
     c = h.Context(0)

@@ -80,6 +80,12 @@ struct batch_state {
     bool bal_pending = false;                 /* h_fstats[bal_slot] will hold the times of a launch dealt with bal_used_* */
     uint32_t bal_used_mask = 0xFFu;
     double bal_used_extra = 0.0;              /* work of a fast block relative to a slow one, minus one, in that launch */
+    /* k_fir_fused: the rows of every unit (frame, segment, strip), cut by XCD speed */
+    uint32_t *d_unit_rows = nullptr, *h_unit_rows = nullptr;
+    size_t unit_rows_cap = 0;                 /* in units */
+    std::vector<uint32_t> dev_unit_rows;      /* what d_unit_rows holds */
+    bool ffb_pending = false;                 /* h_fstats[bal_slot] will hold the XCD run times of a k_fir_fused launch ... */
+    double ffb_work[8] = {0, 0, 0, 0, 0, 0, 0, 0}; /* ... in which a block of XCD x had this much work (steps, mean) */
     frame_stats *d_fstats = nullptr, *h_fstats = nullptr;
     frame_stats *m_fstats = nullptr; /* h_fstats as the device sees it (pinned host memory): k_stats_final of a batch writes there, no copy command */
     frame_stats *fs_out = nullptr;   /* where run_frames() has the statistics written: d_fstats, or m_fstats for an enqueued batch */
@@ -123,6 +129,8 @@ struct h2y_ctx {
     double bal_speed[8] = {1, 1, 1, 1, 1, 1, 1, 1};
     uint32_t bal_mask = 0xFFu;                /* the XCDs that get the second part */
     double bal_rho = 1.0;                     /* how much more work a fast block gets than a slow one */
+    bool ffb_have = false;                    /* k_fir_fused has its own speeds: it is vector-issue bound, the XCDs differ more on it */
+    double ffb_speed[8] = {1, 1, 1, 1, 1, 1, 1, 1};
     int t1_skip = 0, t1_skip_len = 0;
     bool cur_skip_t1 = false;
     /* h2y_ctx_set_option(): tuning / test knobs, per context (nothing is read from the environment) */
@@ -447,6 +455,27 @@ int ensure_tfn(h2y_ctx *ctx, int fn)
     return 0;
 }
 
+/* after a k_fir_fused launch whose block clocks came back: speed of each XCD = steps a wave of it had / time it took */
+void ffb_update(h2y_ctx *ctx)
+{
+    if (!ctx->b->ffb_pending) return;
+    ctx->b->ffb_pending = false;
+    double sp[8], mean = 0.0;
+    for (int x = 0; x < 8; x++) {
+        const double t = reinterpret_cast<const float *>(ctx->b->h_fstats + ctx->b->bal_slot)[x];
+        if (!(t > 0.0) || !(ctx->b->ffb_work[x] > 0.0)) return;
+        sp[x] = ctx->b->ffb_work[x] / t;
+        mean += sp[x] / 8.0;
+    }
+    for (int x = 0; x < 8; x++) {
+        double v = sp[x] / mean;
+        if (v < 0.75) v = 0.75;
+        if (v > 1.25) v = 1.25;
+        ctx->ffb_speed[x] = ctx->ffb_have ? 0.5 * ctx->ffb_speed[x] + 0.5 * v : v;
+    }
+    ctx->ffb_have = true;
+}
+
 /* launch fused (+FIR) over frames [0,n) whose frame_io entries are in h_frames */
 int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, const assumed_stats *d_assumed,
                const assumed_stats *known, bool check, int fstats_offset, bool time_it)
@@ -531,6 +560,86 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
             fa.pp = pp;
             const uint32_t blocks_needed = (uint32_t)((units + 15u) / 16u);
             const int grid = (int)(blocks_needed < (uint32_t)ctx->n_cu ? blocks_needed : (uint32_t)ctx->n_cu);
+            /* Rows by XCD speed.  The XCDs of a card are not equally fast on this kernel (measured: the odd ones finish
+             * 11 % later on equal shares), a wave's units are fixed, and a launch ends with its slowest wave.  Strips are
+             * independent, so every (frame, strip) column is cut into its segments in proportion to the speeds of the XCDs
+             * its units will run on (unit u -> wave u % GW -> block / 16 -> XCD block % 8), lead-in steps included.  The
+             * speeds come from the block clocks of earlier launches (ffb_update()). */
+            fa.unit_rows = nullptr;
+            fa.block_clock = nullptr;
+            const bool full = grid == ctx->n_cu && grid % 8 == 0;
+            fa.mix_xcds = grid % 8 == 0 ? 1u : 0u;
+            const bool clocks = full && time_it;
+            double sp[8];
+            bool weigh = full && nseg >= 2 && ctx->opt_bal_mode != 1 && (ctx->opt_bal_mode == 2 || ctx->ffb_have);
+            for (int x = 0; x < 8; x++)
+                sp[x] = ctx->opt_bal_mode == 2 ? (((ctx->opt_bal_mask >> x) & 1u) ? ctx->opt_bal_rho : 1.0) : ctx->ffb_speed[x];
+            double work[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (weigh || clocks) {
+                const uint32_t gwaves = (uint32_t)grid * 16u;
+                if (weigh) {
+                    if (ctx->b->unit_rows_cap < units) {
+                        if (ctx->b->d_unit_rows) HIP_TRY(ctx, hipFree(ctx->b->d_unit_rows));
+                        if (ctx->b->h_unit_rows) HIP_TRY(ctx, hipHostFree(ctx->b->h_unit_rows));
+                        ctx->b->d_unit_rows = ctx->b->h_unit_rows = nullptr;
+                        ctx->b->unit_rows_cap = 0;
+                        ctx->b->dev_unit_rows.clear();
+                        HIP_TRY(ctx, hipMalloc((void **)&ctx->b->d_unit_rows, units * sizeof(uint32_t)));
+                        HIP_TRY(ctx, hipHostMalloc((void **)&ctx->b->h_unit_rows, units * sizeof(uint32_t), hipHostMallocDefault));
+                        ctx->b->unit_rows_cap = units;
+                    }
+                }
+                std::vector<uint32_t> rows((size_t)units);
+                std::vector<int> xs;
+                for (uint32_t f = 0; f < (uint32_t)n; f++)
+                    for (uint32_t st = 0; st < ns; st++) {
+                        double ssum = 0.0, csum = 0.0;
+                        xs.resize(nseg);
+                        for (uint32_t i = 0; i < nseg; i++) {
+                            const uint32_t u = (f * nseg + i) * ns + st;
+                            xs[i] = (int)(h2y_firf_vblock((u % gwaves) / 16u) % 8u); /* the block that works as virtual block (u % GW) / 16 */
+                            ssum += weigh ? sp[xs[i]] : 1.0;
+                            csum += i == 0 ? 3.0 : 6.0;
+                        }
+                        const double T = ((double)h2 + csum) / ssum;
+                        uint32_t j0 = 0;
+                        for (uint32_t i = 0; i < nseg; i++) {
+                            const uint32_t u = (f * nseg + i) * ns + st;
+                            uint32_t j1;
+                            if (!weigh) j1 = (i + 1u) * seg_rows < h2 ? (i + 1u) * seg_rows : h2;
+                            else if (i + 1u == nseg) j1 = h2;
+                            else {
+                                double r = (weigh ? sp[xs[i]] : 1.0) * T - (i == 0 ? 3.0 : 6.0);
+                                const uint32_t left = nseg - 1u - i; /* segments after this one: eight rows each at least */
+                                if (r < 8.0) r = 8.0;
+                                j1 = j0 + (uint32_t)(r + 0.5);
+                                if (j1 + 8u * left > h2) j1 = h2 - 8u * left;
+                                if (j1 <= j0) j1 = j0 + 1u;
+                            }
+                            rows[u] = j0 | (j1 << 16);
+                            work[xs[i]] += (double)(j1 - j0) + 3.0 + (j0 < 3u ? (double)j0 : 3.0);
+                            j0 = j1;
+                        }
+                    }
+                for (int x = 0; x < 8; x++) work[x] /= (double)(gwaves / 8u); /* steps per wave of that XCD */
+                if (weigh) {
+                    if (ctx->b->dev_unit_rows != rows) {
+                        memcpy(ctx->b->h_unit_rows, rows.data(), units * sizeof(uint32_t));
+                        HIP_TRY(ctx, hipMemcpyAsync(ctx->b->d_unit_rows, ctx->b->h_unit_rows, units * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+                        ctx->b->dev_unit_rows = rows;
+                    }
+                    fa.unit_rows = ctx->b->d_unit_rows;
+                }
+            }
+            if (clocks) {
+                const size_t need = (size_t)2 * grid * sizeof(unsigned long long);
+                if (ctx->b->clock_cap < need) {
+                    rc = ensure(ctx, ctx->b->d_clock, ctx->b->clock_cap, need);
+                    if (rc) return rc;
+                    HIP_TRY(ctx, hipMemsetAsync(ctx->b->d_clock, 0, need, ctx->stream)); /* k_stats_final clears the finish entries from here on */
+                }
+                fa.block_clock = ctx->b->d_clock;
+            }
             const bool ev = time_it && ctx->b->n_ev < kMaxEvents;
             if (ev) {
                 HIP_TRY(ctx, hipEventRecord(ctx->b->ev[ctx->b->n_ev][0], ctx->stream));
@@ -556,10 +665,15 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
             fin.check = check ? 1 : 0;
             fin.assumed = d_assumed;
             fin.publish = nullptr;
-            fin.block_clock = nullptr;
-            fin.grid = 0;
-            fin.xcd_time = nullptr;
+            fin.block_clock = clocks ? ctx->b->d_clock : nullptr;
+            fin.grid = grid;
+            fin.xcd_time = reinterpret_cast<float *>(ctx->b->fs_out + fstats_offset + n); /* the caller's copy of the statistics takes one entry more */
             HIP_TRY(ctx, h2y_launch_stats_final(n, ctx->stream, fin));
+            if (clocks) {
+                ctx->b->bal_slot = fstats_offset + n;
+                ctx->b->ffb_pending = true;
+                for (int x = 0; x < 8; x++) ctx->b->ffb_work[x] = work[x];
+            }
             return 0;
         }
     }
@@ -1000,6 +1114,8 @@ void h2y_ctx_destroy(h2y_ctx *ctx)
         (void)hipFree(b.d_redo);
         (void)hipFree(b.d_low);
         (void)hipFree(b.d_clock);
+        (void)hipFree(b.d_unit_rows);
+        (void)hipHostFree(b.h_unit_rows);
         (void)hipFree(b.d_fstats);
         (void)hipHostFree(b.h_fstats);
         (void)hipFree(b.d_assumed);
@@ -1130,12 +1246,16 @@ int h2y_batch_finish(h2y_ctx *ctx, int *n_redone)
     ctx->last_ms = ms;
     ctx->last_launches = ctx->b->n_ev;
 #ifdef H2Y_BLOCK_TIMES
-    if (const char *e = getenv("H2Y_BLOCK_TIMES_FILE")) h2y_dump_block_times(e);
+    if (const char *e = getenv("H2Y_BLOCK_TIMES_FILE")) {
+        if (!strcmp(ctx->last_name, "k_fir_fused")) h2y_dump_ff_block_times(e);
+        else h2y_dump_block_times(e);
+    }
 #endif
     int redone = 0;
     const h2y_desc *d = &ctx->b->p_desc;
     t1_end_batch(ctx, d, ctx->b->h_fstats, ctx->b->p_n);
     balance_update(ctx);
+    ffb_update(ctx);
     if (ctx->b->p_check) {
         for (int f = 0; f < ctx->b->p_n; f++) {
             if (!ctx->b->h_fstats[f].mismatch) continue;

@@ -35,6 +35,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <stdio.h>
+
 #include "h2y_device.h"
 
 #define FF_THREADS 1024
@@ -134,9 +136,26 @@ struct ff_hist {
 #define FF_TIER_LUT16 1
 __device__ __forceinline__ uint32_t half_bits_of(float v) { return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)v); } /* exact: v was a half */
 
+#ifdef H2Y_BLOCK_TIMES /* timing experiments only: when does each block start and finish? (tools/blocktimes.py) */
+__device__ unsigned long long g_ff_block_times[2 * 1024];
+void h2y_dump_ff_block_times(const char *path)
+{
+    static unsigned long long h[2 * 1024];
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ff_block_times), sizeof h) != hipSuccess) return;
+    FILE *f = fopen(path, "w");
+    if (!f) return;
+    for (int i = 0; i < 1024; i++) fprintf(f, "%d %llu %llu\n", i, h[2 * i], h[2 * i + 1]);
+    fclose(f);
+}
+#endif
+
 template <int IN_KIND, int MODE, int PIPE, int TIER>
 __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
 {
+#ifdef H2Y_BLOCK_TIMES
+    if (threadIdx.x == 0) { g_ff_block_times[2 * blockIdx.x] = wall_clock64(); g_ff_block_times[2 * blockIdx.x + 1] = 0ull; }
+#endif
+    if (a.block_clock && threadIdx.x == 0) a.block_clock[2 * blockIdx.x] = wall_clock64();
     __shared__ pq_rec1 s_t1[TIER == FF_TIER_T1 ? H2Y_T1_NREC : 1];
     __shared__ pq_recA s_t2[TIER == FF_TIER_T1 ? 2 * H2Y_PQ_NREC : 1]; /* A records, then B records */
     __shared__ float s_lut[TIER == FF_TIER_LUT16 ? H2Y_LUT16_N : 1];
@@ -156,7 +175,8 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
     typedef in_traits<IN_KIND> IN;
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     const uint32_t GW = gridDim.x * (FF_THREADS / WAVE);
-    const uint32_t gw = __builtin_amdgcn_readfirstlane(blockIdx.x * (FF_THREADS / WAVE) + threadIdx.x / WAVE); /* uniform, and known to be */
+    const uint32_t vblock = a.mix_xcds ? ((blockIdx.x & ~6u) | ((blockIdx.x & 2u) << 1) | ((blockIdx.x & 4u) >> 1)) : blockIdx.x; /* h2y_firf_vblock() */
+    const uint32_t gw = __builtin_amdgcn_readfirstlane(vblock * (FF_THREADS / WAVE) + threadIdx.x / WAVE); /* uniform, and known to be */
     const uint32_t W = a.width, H = a.height, WQ = a.wq, H2 = H >> 1;
     const uint32_t npix = W * H, ncb = (W >> 1) * (H >> 1);
     const int32_t maxcv = (int32_t)pp.maxCV, clo = (int32_t)pp.clo_s, chi = (int32_t)pp.chi_s; /* float input: down_shift == 0 */
@@ -168,7 +188,12 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
         const uint32_t f = __builtin_amdgcn_readfirstlane(u / a.units_per_frame), r = u - f * a.units_per_frame;
         const uint32_t seg = __builtin_amdgcn_readfirstlane(r / a.n_strips), strip = r - seg * a.n_strips;
         const frame_io io = uniform_io(a.frames + f);
-        const uint32_t j0 = seg * a.seg_rows, j1 = j0 + a.seg_rows < H2 ? j0 + a.seg_rows : H2;   /* chroma rows [j0, j1) are this unit's */
+        uint32_t j0 = seg * a.seg_rows, j1 = j0 + a.seg_rows < H2 ? j0 + a.seg_rows : H2;   /* chroma rows [j0, j1) are this unit's */
+        if (a.unit_rows) { /* the host's own cut of this (frame, strip) column (weights by XCD speed) */
+            const uint32_t rw = __builtin_amdgcn_readfirstlane(a.unit_rows[u]);
+            j0 = rw & 0xFFFFu;
+            j1 = rw >> 16;
+        }
         const uint32_t s_begin = j0 >= 3u ? j0 - 3u : 0u, s_end = j1 + 2u;          /* steps: row pairs s_begin .. s_end (those >= H2 are virtual) */
         const int32_t qxu = (int32_t)(FF_OWN_LANES * strip + lane) - 2;             /* this lane's quad column, before clamping */
         const uint32_t qx = (uint32_t)min(max(qxu, 0), (int32_t)WQ - 1);
@@ -328,6 +353,10 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
             if (PIPE == H2Y_PIPE_PQ_IDENT && a.low_flag && low_m != 0) a.low_flag[f] = 1u;
         }
     }
+    if (a.block_clock && (threadIdx.x & (WAVE - 1)) == 0) atomicMax(&a.block_clock[2 * blockIdx.x + 1], (unsigned long long)wall_clock64());
+#ifdef H2Y_BLOCK_TIMES
+    if ((threadIdx.x & (WAVE - 1)) == 0) atomicMax(&g_ff_block_times[2 * blockIdx.x + 1], (unsigned long long)wall_clock64());
+#endif
 }
 
 /* ---- launch ------------------------------------------------------------- */

@@ -141,7 +141,13 @@ struct firf_args {
     uint32_t width, height;
     uint32_t wq;              /* width / 4 */
     uint32_t n_strips;        /* ceil(wq / 60) */
-    uint32_t n_seg, seg_rows; /* segments per frame, chroma rows per segment (the last may be shorter) */
+    uint32_t n_seg, seg_rows; /* segments per frame, chroma rows per segment (the last may be shorter): the even cut */
+    const uint32_t *unit_rows; /* [total_units]: first chroma row | one past the last << 16 of every unit, or NULL for the even cut.
+                                  Strips are independent of each other, so every (frame, strip) column may be cut its own way:
+                                  the host gives the units that run on slower XCDs fewer rows */
+    unsigned long long *block_clock; /* as fused_args.block_clock */
+    uint32_t mix_xcds;        /* 1 (grid a multiple of 8): block b works as block h2y_firf_vblock(b), so that the segments of one
+                                 (frame, strip) column land on XCDs of both halves of the card and of both parities */
     uint32_t units_per_frame; /* n_seg * n_strips */
     uint32_t total_units;     /* n_frames * units_per_frame */
     const void *table, *table1;
@@ -164,6 +170,7 @@ struct up_args { /* k_up444: one or two chroma planes, (width/2 x height/2) -> (
 
 #ifdef H2Y_BLOCK_TIMES
 void h2y_dump_block_times(const char *path); /* timing experiments only */
+void h2y_dump_ff_block_times(const char *path);
 #endif
 int h2y_fused_threads(const fused_variant &v);
 const char *h2y_fused_name(const fused_variant &v);
@@ -175,6 +182,9 @@ hipError_t h2y_launch_stats(int in_kind, int grid, hipStream_t st, const stats_a
 hipError_t h2y_launch_stats_final(int n_frames, hipStream_t st, const final_args &a);
 hipError_t h2y_launch_fir420(hipStream_t st, const fir_args &a);
 hipError_t h2y_launch_inverse(int grid, hipStream_t st, const inverse_args &a);
+/* k_fir_fused: bits 1 and 2 of the block number exchanged (an involution on [0, 8k)).  Block b runs on XCD b % 8; with four
+ * segments per column, b = 4 f + segment would give a column the XCDs {0..3} or {4..7} -- after the exchange {0,1,4,5} or {2,3,6,7} */
+static inline uint32_t h2y_firf_vblock(uint32_t b) { return (b & ~6u) | ((b & 2u) << 1) | ((b & 4u) >> 1); }
 hipError_t h2y_launch_fir_fused(int in_kind, int mode, bool ident, bool lut16, int grid, hipStream_t st, const firf_args &a);
 hipError_t h2y_launch_up444(hipStream_t st, const up_args &a);
 hipError_t h2y_launch_box420(hipStream_t st, const uint16_t *src, uint16_t *dst, int W, int H);

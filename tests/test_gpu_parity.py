@@ -1169,3 +1169,39 @@ def test_context_options_and_variant_names(oracle):
                 c.set_option("balance", "0xFF,1.2")  # every XCD fast is no split at all
         finally:
             c.close()
+
+
+@pytest.mark.parametrize("balance", ["0x55,1.12", "0xAA,1.25", "0x0F,1.2"])
+def test_fir_fused_rows_by_xcd_speed(oracle, balance):
+    """k_fir_fused cuts every (frame, strip) column into its segments in proportion to the speeds of the XCDs its units run
+    on (a launch ends with its slowest wave, and the XCDs differ).  Here the weights are fixed through the "balance" option,
+    strong ones included, on a batch that fills the grid (16 x 4K: 4096 units): segments of unequal length, every row of
+    every frame still produced exactly once -- frame 0 is the SURVEY 8c known answer, two more go through the oracle."""
+    import torch
+
+    case = KNOWN["cases"]["C2_4k_2020_12b_fir"]
+    d = h.make_desc(**case["desc"])
+    n = 16
+    host = {k: oracle.synth_frame(d.width, d.height, k) for k in (0, 5, 11)}
+    gen = None
+    dev_in = []
+    for k in range(n):
+        planes = host[k] if k in host else oracle.synth_frame(d.width, d.height, k)
+        dev_in.append([torch.from_numpy(p).cuda() for p in planes])
+    c = h.Context(0)
+    c.set_option("fir", "fused")
+    c.set_option("balance", balance)
+    try:
+        for rnd in range(2):
+            dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda") for _ in range(n)]
+            torch.cuda.synchronize()
+            c.convert_batch(d, dev_in, dev_out)
+            assert c.last_kernel_name() == "k_fir_fused", c.last_kernel_variant()
+            assert _md5(dev_out[0].cpu().numpy().view(np.uint16)) == case["md5"]
+            od = _to_oracle_desc(d)
+            for k in (5, 11):
+                got = dev_out[k].cpu().numpy().view(np.uint16)
+                want = oracle.convert_frame(od, host[k])
+                assert np.array_equal(got, want), f"{balance} round {rnd} frame {k}: {np.count_nonzero(got != want)} samples differ"
+    finally:
+        c.close()

@@ -467,7 +467,7 @@ def main() -> int:
     # ---- secondary passes (N = 1): the other resampler and the other BASELINE configs -------
     if world == 1 and not args.no_extra:
         others = {}
-        sec_steps, sec_warm = max(5, args.steps // 2), max(3, args.warmup // 2)
+        sec_steps, sec_warm = max(10, args.steps // 2), max(8, args.warmup)  # (the XCD weights settle within the first few launches)
         plan = []
         if is420:
             plan.append((args.workload, "fir" if args.resampler == "box" else "box", F))

@@ -77,9 +77,11 @@ struct batch_state {
     unsigned long long *d_clock = nullptr;
     size_t clock_cap = 0;
     int bal_slot = 0;                         /* the eight run times travel in the frame_stats entry after the batch's last */
-    bool bal_pending = false;                 /* h_fstats[bal_slot] will hold the times of a launch dealt with bal_used_* */
-    uint32_t bal_used_mask = 0xFFu;
-    double bal_used_extra = 0.0;              /* work of a fast block relative to a slow one, minus one, in that launch */
+    bool bal_pending = false;                 /* h_fstats[bal_slot] will hold the times of a launch dealt with bal_work */
+    double bal_work[8] = {1, 1, 1, 1, 1, 1, 1, 1}; /* relative work a block of XCD x had in that launch */
+    uint32_t *d_ranges = nullptr, *h_ranges = nullptr; /* fused_args.slice_ranges: [blocks of a group + 1] */
+    size_t ranges_cap = 0;
+    std::vector<uint32_t> dev_ranges;         /* what d_ranges holds */
     /* k_fir_fused: the rows of every unit (frame, segment, strip), cut by XCD speed */
     uint32_t *d_unit_rows = nullptr, *h_unit_rows = nullptr;
     size_t unit_rows_cap = 0;                 /* in units */
@@ -127,8 +129,6 @@ struct h2y_ctx {
      * of each XCD; the shares of the next launch follow the speeds seen (balance_update()). */
     bool bal_have = false;
     double bal_speed[8] = {1, 1, 1, 1, 1, 1, 1, 1};
-    uint32_t bal_mask = 0xFFu;                /* the XCDs that get the second part */
-    double bal_rho = 1.0;                     /* how much more work a fast block gets than a slow one */
     bool ffb_have = false;                    /* k_fir_fused has its own speeds: it is vector-issue bound, the XCDs differ more on it */
     double ffb_speed[8] = {1, 1, 1, 1, 1, 1, 1, 1};
     int t1_skip = 0, t1_skip_len = 0;
@@ -381,29 +381,8 @@ int out_kind_of(const h2y_desc *d)
     return d->chroma_resampler_type == 0 ? H2Y_OUT_420BOX : H2Y_OUT_444TMP;
 }
 
-/* the split of a frame's chunks for this launch: chunks [0, *chunks_a) round all blocks, the rest round the fast ones */
-void balance_for_launch(const h2y_ctx *ctx, uint32_t cpf, uint32_t *mask, uint32_t *chunks_a, double *extra)
-{
-    uint32_t m = ctx->bal_mask;
-    double rho = ctx->bal_rho;
-    if (ctx->opt_bal_mode == 1) { m = 0xFFu; rho = 1.0; }
-    if (ctx->opt_bal_mode == 2) { m = ctx->opt_bal_mask; rho = ctx->opt_bal_rho; }
-    *mask = 0xFFu;
-    *chunks_a = cpf;
-    *extra = 0.0;
-    if (m == 0xFFu || !(rho > 1.0)) return;
-    const double fshare = (double)__builtin_popcount(m) / 8.0; /* Gf / G */
-    /* fast block: cpfA / G + cpfB / Gf = rho * cpfA / G  =>  cpfA = cpf / (1 + (rho - 1) * Gf / G) */
-    uint32_t ca = (uint32_t)((double)cpf / (1.0 + (rho - 1.0) * fshare) + 0.5);
-    if (ca > cpf) ca = cpf;
-    if (ca < 1) ca = 1;
-    if (ca == cpf) return;
-    *mask = m;
-    *chunks_a = ca;
-    *extra = ((double)(cpf - ca) / fshare) / (double)ca; /* the ratio actually dealt, minus one */
-}
-
-/* after a launch whose block clocks came back: speeds per XCD, and from them the next launch's shares */
+/* after a launch whose block clocks came back: speed of each XCD = the share its blocks had / the time they took;
+ * the next launch's slice ranges follow the speeds (run_frames()) */
 void balance_update(h2y_ctx *ctx)
 {
     if (!ctx->b->bal_pending) return;
@@ -412,32 +391,16 @@ void balance_update(h2y_ctx *ctx)
     for (int x = 0; x < 8; x++) {
         const double t = reinterpret_cast<const float *>(ctx->b->h_fstats + ctx->b->bal_slot)[x];
         if (!(t > 0.0)) return; /* grid smaller than a round of XCDs, or nothing measured */
-        const double w = ((ctx->b->bal_used_mask >> x) & 1u) && ctx->b->bal_used_mask != 0xFFu ? 1.0 + ctx->b->bal_used_extra : 1.0;
-        sp[x] = w / t;
+        sp[x] = ctx->b->bal_work[x] / t;
         mean += sp[x] / 8.0;
     }
-    double lo = 1e30, hi = 0.0;
     for (int x = 0; x < 8; x++) {
-        sp[x] /= mean;
-        ctx->bal_speed[x] = ctx->bal_have ? 0.5 * ctx->bal_speed[x] + 0.5 * sp[x] : sp[x];
-        lo = ctx->bal_speed[x] < lo ? ctx->bal_speed[x] : lo;
-        hi = ctx->bal_speed[x] > hi ? ctx->bal_speed[x] : hi;
+        double v = sp[x] / mean;
+        if (v < 0.75) v = 0.75;
+        if (v > 1.25) v = 1.25;
+        ctx->bal_speed[x] = ctx->bal_have ? 0.5 * ctx->bal_speed[x] + 0.5 * v : v;
     }
     ctx->bal_have = true;
-    ctx->bal_mask = 0xFFu;
-    ctx->bal_rho = 1.0;
-    if (hi < 1.01 * lo) return; /* level: one part */
-    const double thr = 0.5 * (hi + lo);
-    uint32_t m = 0;
-    double sf = 0.0, ss = 0.0;
-    int nf = 0;
-    for (int x = 0; x < 8; x++)
-        if (ctx->bal_speed[x] > thr) { m |= 1u << x; sf += ctx->bal_speed[x]; nf++; }
-        else ss += ctx->bal_speed[x];
-    if (nf == 0 || nf == 8) return;
-    ctx->bal_mask = m;
-    ctx->bal_rho = (sf / nf) / (ss / (8 - nf));
-    if (ctx->bal_rho > 1.5) ctx->bal_rho = 1.5;
 }
 
 /* the table of transfer function fn on the device (built on the host the first time it is asked for) */
@@ -748,8 +711,43 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         /* XCD-aware rounds and their weights; the block clocks of timed launches feed balance_update() */
         const bool xcd_layout = h2y_fused_grouped(var) && grid % (8 * groups) == 0;
         uint32_t fast_mask = 0xFFu, chunks_a = g.chunks;
-        double extra = 0.0;
-        if (xcd_layout) balance_for_launch(ctx, g.chunks, &fast_mask, &chunks_a, &extra);
+        /* Slices by XCD speed: block i of a group takes one contiguous run of every frame's 64-tile slices, as long as
+         * the measured speed of its XCD says (block i of a group runs on XCD i % 8 under xcd_layout).  "off": the even
+         * round-robin dealing of frame_walk. */
+        const uint32_t *d_slice_ranges = nullptr;
+        double work[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+        if (xcd_layout && ctx->opt_bal_mode != 1) {
+            const uint32_t G = (uint32_t)grid / (uint32_t)groups, nslices = (g.tiles + 63u) / 64u;
+            double sp[8], mean = 0.0;
+            for (int x = 0; x < 8; x++) {
+                sp[x] = ctx->opt_bal_mode == 2 ? (((ctx->opt_bal_mask >> x) & 1u) ? ctx->opt_bal_rho : 1.0) : (ctx->bal_have ? ctx->bal_speed[x] : 1.0);
+                mean += sp[x] / 8.0;
+            }
+            for (int x = 0; x < 8; x++) work[x] = sp[x] / mean;
+            std::vector<uint32_t> r((size_t)G + 1u);
+            double cum = 0.0;
+            const double tot = mean * (double)G;
+            for (uint32_t i = 0; i <= G; i++) {
+                r[i] = i == G ? nslices : (uint32_t)(cum / tot * (double)nslices + 0.5);
+                if (i < G) cum += sp[i % 8u];
+            }
+            if (ctx->b->ranges_cap < r.size()) {
+                if (ctx->b->d_ranges) HIP_TRY(ctx, hipFree(ctx->b->d_ranges));
+                if (ctx->b->h_ranges) HIP_TRY(ctx, hipHostFree(ctx->b->h_ranges));
+                ctx->b->d_ranges = ctx->b->h_ranges = nullptr;
+                ctx->b->ranges_cap = 0;
+                ctx->b->dev_ranges.clear();
+                HIP_TRY(ctx, hipMalloc((void **)&ctx->b->d_ranges, 1025 * sizeof(uint32_t)));
+                HIP_TRY(ctx, hipHostMalloc((void **)&ctx->b->h_ranges, 1025 * sizeof(uint32_t), hipHostMallocDefault));
+                ctx->b->ranges_cap = 1025;
+            }
+            if (ctx->b->dev_ranges != r) {
+                memcpy(ctx->b->h_ranges, r.data(), r.size() * sizeof(uint32_t));
+                HIP_TRY(ctx, hipMemcpyAsync(ctx->b->d_ranges, ctx->b->h_ranges, r.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+                ctx->b->dev_ranges = r;
+            }
+            d_slice_ranges = ctx->b->d_ranges;
+        }
         const bool clocks = xcd_layout && time_it;
         if (clocks) {
             const size_t need = (size_t)2 * grid * sizeof(unsigned long long);
@@ -764,6 +762,7 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         a.fast_mask = fast_mask;
         a.chunks_a = chunks_a;
         a.block_clock = clocks ? ctx->b->d_clock : nullptr;
+        a.slice_ranges = d_slice_ranges;
         a.redo_count = t1 ? ctx->b->d_redo : nullptr;
         a.low_flag = approx ? ctx->b->d_low : nullptr;
         a.frames = ctx->b->d_frames + ctx->slot_base + f0;
@@ -833,8 +832,7 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         if (clocks) {
             ctx->b->bal_slot = fstats_offset + n;
             ctx->b->bal_pending = true;
-            ctx->b->bal_used_mask = fast_mask;
-            ctx->b->bal_used_extra = extra;
+            for (int x = 0; x < 8; x++) ctx->b->bal_work[x] = work[x];
         }
         if (out_kind == H2Y_OUT_444TMP) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev_fused[half], ctx->stream));
@@ -1114,6 +1112,8 @@ void h2y_ctx_destroy(h2y_ctx *ctx)
         (void)hipFree(b.d_redo);
         (void)hipFree(b.d_low);
         (void)hipFree(b.d_clock);
+        (void)hipFree(b.d_ranges);
+        (void)hipHostFree(b.h_ranges);
         (void)hipFree(b.d_unit_rows);
         (void)hipHostFree(b.h_unit_rows);
         (void)hipFree(b.d_fstats);
@@ -1700,6 +1700,7 @@ int h2y_matrix_convert(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3
     a.fast_mask = 0xFFu;
     a.chunks_a = g.chunks;
     a.block_clock = nullptr;
+    a.slice_ranges = nullptr;
     a.table = ctx->d_table;
     a.table_src = a.table_dst = nullptr; /* (a generic transfer pair takes the careful tier in this stage entry) */
     a.lut16 = ctx->d_lut16;

@@ -65,6 +65,9 @@ struct fused_args {
     uint32_t fast_mask;       /* xcd_layout: the XCDs (bit = blockIdx.x % 8) whose blocks take the second part of every frame */
     uint32_t chunks_a;        /* xcd_layout: chunks [0, chunks_a) of a frame go round all blocks, the rest round the fast ones */
     unsigned long long *block_clock; /* [gridDim.x][2]: start, finish (wall_clock64) of each block, or NULL; finish entries zero at launch */
+    const uint32_t *slice_ranges; /* xcd_layout, loop-form kernels: [gridDim.x / groups + 1] first 64-tile slice of every block of a group
+                                     (the last entry = slices per frame): block i of a group takes slices [r[i], r[i+1]) of each of the
+                                     group's frames; NULL = the round-robin dealing of frame_walk */
     const void *table;        /* pq_recA[NREC] then pq_recB[NREC] */
     const void *table_src, *table_dst; /* k_fused, generic transfer pair (pp.convert_transfer == 2): the two stages' tables in the same
                                           format (tfn_build_table), or NULL for a stage that is the identity */

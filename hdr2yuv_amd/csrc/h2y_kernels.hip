@@ -328,21 +328,45 @@ __device__ __forceinline__ size_t walk_slot(const frame_walk &fw, uint32_t waves
 #define H2Y_CLAIM_FRAMES 128
 struct wave_deal { /* a block's share of one frame, in slices */
     uint32_t kA, kB, G, Gf, nA, total; /* first chunks and strides of the two parts, chunks in part A, slices in all */
+    uint32_t s0;                       /* ranged form: the block's first slice */
+    bool ranged;
     __device__ __forceinline__ void set(const frame_walk &fw, uint32_t ka, uint32_t kb, uint32_t wpb)
     {
         kA = ka; kB = kb; G = fw.G; Gf = fw.Gf;
         nA = fw.count_a(ka);
         total = (nA + fw.count_b(kb)) * wpb;
+        ranged = false;
+        s0 = 0;
+    }
+    /* Ranged form (fused_args.slice_ranges): the block owns the slices [first, first + count) of every frame of its
+     * group -- one contiguous run of 64-tile slices, as long as its XCD is fast (the host cuts a frame's slices among the
+     * blocks of a group by the measured speeds of their XCDs: balance_for_launch() in h2y_api.hip). */
+    __device__ __forceinline__ void set_range(uint32_t first, uint32_t count)
+    {
+        kA = kB = 0; G = Gf = 1; nA = 0;
+        s0 = first;
+        total = count;
+        ranged = true;
     }
     /* first tile of slice i (WPB slices of 64 tiles per chunk of THREADS tiles) */
     template <int THREADS> __device__ __forceinline__ uint32_t tile0(uint32_t i) const
     {
         constexpr uint32_t WPB = THREADS / WAVE;
+        if (ranged) return (s0 + i) * WAVE;
         const uint32_t j = i / WPB, sub = i % WPB;
         const uint32_t k = j < nA ? kA + j * G : kB + (j - nA) * Gf;
         return k * THREADS + sub * WAVE;
     }
 };
+/* this block's run of slices, if the launch deals by ranges: [group-relative block number] and the next entry */
+__device__ __forceinline__ bool block_range(const fused_args &a, const frame_walk &fw, uint32_t &first, uint32_t &count)
+{
+    first = count = 0;
+    if (!a.slice_ranges) return false;
+    first = __builtin_amdgcn_readfirstlane(a.slice_ranges[fw.bi]);
+    count = __builtin_amdgcn_readfirstlane(a.slice_ranges[fw.bi + 1u]) - first;
+    return true;
+}
 /* draw a number: lane 0 adds to the counter, the other lanes to scratch words of their own (no branch) */
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 __device__ __forceinline__ uint32_t wave_claim(uint32_t *ctr, uint32_t *scratch /* [WAVE] */, bool real)
@@ -443,15 +467,23 @@ __global__ __launch_bounds__(H2Y_LOOP_THREADS) void k_fused2(fused_args a)
     typedef in_traits<IN_KIND> IN;
     frame_walk fw;
     uint32_t fo = 0, tick = 0; /* waves take their tiles by ticket: see wave_deal */
-    for (walk_init(fw, a); fw.f < a.n_frames; fw.advance(), fo++) {
+    walk_init(fw, a);
+    uint32_t r_first, r_count;
+    const bool ranged = block_range(a, fw, r_first, r_count);
+    for (; fw.f < a.n_frames; fw.advance(), fo++) {
         const int f = fw.f;
         const frame_io io = uniform_io(a.frames + f);
         const frame_io io_next = uniform_io(a.frames + (fw.has_next() ? f + (int)fw.NG : f));
         mm6 mm;
         mm.reset();
         wave_deal deal, deal_n;
-        deal.set(fw, fw.kA, fw.kB, H2Y_LOOP_THREADS / WAVE);
-        deal_n.set(fw, fw.kA_n, fw.kB_n, H2Y_LOOP_THREADS / WAVE);
+        if (ranged) {
+            deal.set_range(r_first, r_count);
+            deal_n.set_range(r_first, r_count);
+        } else {
+            deal.set(fw, fw.kA, fw.kB, H2Y_LOOP_THREADS / WAVE);
+            deal_n.set(fw, fw.kA_n, fw.kB_n, H2Y_LOOP_THREADS / WAVE);
+        }
         if (!have) tick = wave_claim(&s_claim[fo], s_scratch, true);
         bool more = tick < deal.total; /* (a slice carried over from the previous frame is always below the total) */
         if (!have && more) {
@@ -690,7 +722,10 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
     uint32_t fo = 0;   /* ordinal of the frame among the group's: its counter is s_claim[fo] */
     uint32_t tick = 0; /* the slice in hand, if hold: of the frame the loop is at (or about to enter) */
     bool hold = false; /* (have implies hold: v is tick's tile; a redo pass drops the data, not the slice) */
-    for (walk_init(fw, a); fw.f < a.n_frames; fw.advance(), fo++) {
+    walk_init(fw, a);
+    uint32_t r_first, r_count;
+    const bool ranged = block_range(a, fw, r_first, r_count);
+    for (; fw.f < a.n_frames; fw.advance(), fo++) {
         const int f = fw.f;
         const frame_io io = uniform_io(a.frames + f);
         const frame_io io_next = uniform_io(a.frames + (fw.has_next() ? f + (int)fw.NG : f)); /* for the prefetch across the frame boundary */
@@ -699,8 +734,13 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
         const uint32_t id_base = (uint32_t)f * a.tiles_per_frame;
         uint32_t flagged_f = 0; /* tiles of this frame this wave sent to the list (the host steers by their share) */
         wave_deal deal, deal_n;
-        deal.set(fw, fw.kA, fw.kB, H2Y_T1_THREADS / WAVE);
-        deal_n.set(fw, fw.kA_n, fw.kB_n, H2Y_T1_THREADS / WAVE);
+        if (ranged) {
+            deal.set_range(r_first, r_count);
+            deal_n.set_range(r_first, r_count);
+        } else {
+            deal.set(fw, fw.kA, fw.kB, H2Y_T1_THREADS / WAVE);
+            deal_n.set(fw, fw.kA_n, fw.kB_n, H2Y_T1_THREADS / WAVE);
+        }
         if (!hold) {
             tick = wave_claim(&s_claim[fo], s_scratch, true);
             hold = tick < deal.total;
@@ -964,7 +1004,10 @@ __global__ __launch_bounds__(H2Y_LOOP_THREADS) void k_fused_lut16(fused_args a)
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     frame_walk fw;
     uint32_t fo = 0, tick = 0; /* waves take their tiles by ticket: see wave_deal */
-    for (walk_init(fw, a); fw.f < a.n_frames; fw.advance(), fo++) {
+    walk_init(fw, a);
+    uint32_t r_first, r_count;
+    const bool ranged = block_range(a, fw, r_first, r_count);
+    for (; fw.f < a.n_frames; fw.advance(), fo++) {
         const int f = fw.f;
         const frame_io io = uniform_io(a.frames + f);
         const frame_io io_next = uniform_io(a.frames + (fw.has_next() ? f + (int)fw.NG : f));
@@ -976,8 +1019,13 @@ __global__ __launch_bounds__(H2Y_LOOP_THREADS) void k_fused_lut16(fused_args a)
             mx[c] = 0x00000000u; /* +0: FLT_MIN (1.2e-38) is below the smallest half; (int) of either is 0 */
         }
         wave_deal deal, deal_n;
-        deal.set(fw, fw.kA, fw.kB, H2Y_LOOP_THREADS / WAVE);
-        deal_n.set(fw, fw.kA_n, fw.kB_n, H2Y_LOOP_THREADS / WAVE);
+        if (ranged) {
+            deal.set_range(r_first, r_count);
+            deal_n.set_range(r_first, r_count);
+        } else {
+            deal.set(fw, fw.kA, fw.kB, H2Y_LOOP_THREADS / WAVE);
+            deal_n.set(fw, fw.kA_n, fw.kB_n, H2Y_LOOP_THREADS / WAVE);
+        }
         if (!have) tick = wave_claim(&s_claim[fo], s_scratch, true);
         bool more = tick < deal.total;
         if (!more) have = false;

@@ -1205,3 +1205,82 @@ def test_fir_fused_rows_by_xcd_speed(oracle, balance):
                 assert np.array_equal(got, want), f"{balance} round {rnd} frame {k}: {np.count_nonzero(got != want)} samples differ"
     finally:
         c.close()
+
+
+def test_fuzz_round2_paths_against_oracle(oracle):
+    """Seeded sweep over what round 2 added: the FIR path forced onto k_fir_fused (any width % 4 == 0, any even height,
+    1..12 frames, float or half input, 8..12 bits, both matrices it takes, measured / overridden statistics, fixed XCD
+    weights), every transfer pair through the table tiers (with out-of-table and negative samples), and batches enqueued two
+    at a time with different descriptors behind each other."""
+    import torch
+
+    rng = np.random.default_rng(20261005)
+    tf_codes = [8, 16, 18, 1, 14]
+    c = h.Context(0)
+    c.set_option("fir", "fused")
+    pending = []  # (desc, host frames, device outputs) of batches in flight
+
+    def check(item):
+        d, host, dev_out, tag = item
+        od = _to_oracle_desc(d)
+        for f, fr in enumerate(host):
+            got = dev_out[f].cpu().numpy().view(np.uint16)
+            want = oracle.convert_frame(od, fr)
+            bad = np.flatnonzero(got != want)
+            assert bad.size == 0, (tag, f, int(bad.size), bad[:6].tolist(), c.last_kernel_variant())
+
+    try:
+        for it in range(120):
+            kind = it % 3
+            sample = h.SAMPLE_F32 if rng.random() < 0.75 else h.SAMPLE_F16
+            if kind == 0:  # fused FIR geometries
+                w, hh = int(rng.integers(1, 130)) * 4, int(rng.integers(1, 90)) * 2
+                kw = dict(dst_depth=int(rng.choice([8, 10, 12])), dst_matrix=int(rng.choice([h.MATRIX_BT2020NC, h.MATRIX_BT709, h.MATRIX_YDZDX])),
+                          resampler=1, full_range=int(rng.integers(0, 2)), sample=sample)
+                n = int(rng.integers(1, 13))
+            elif kind == 1:  # transfer pairs, any output form
+                w, hh = int(rng.integers(1, 40)) * 4, int(rng.integers(1, 30)) * 4
+                src, dst = int(rng.choice(tf_codes)), int(rng.choice(tf_codes))
+                kw = dict(dst_depth=int(rng.choice([10, 12, 16])), dst_matrix=int(rng.choice([h.MATRIX_BT2020NC, h.MATRIX_YDZDX, h.MATRIX_Y100])),
+                          src_transfer=src, dst_transfer=dst, chroma=int(rng.choice([h.CHROMA_420, h.CHROMA_444])), resampler=int(rng.integers(0, 2)),
+                          sample=h.SAMPLE_F32)
+                sample = h.SAMPLE_F32
+                n = int(rng.integers(1, 4))
+            else:  # box / 4:4:4 batches with fixed XCD weights now and then
+                w, hh = int(rng.integers(8, 200)) * 4, int(rng.integers(2, 60)) * 4
+                kw = dict(dst_depth=int(rng.choice([10, 12, 16])), dst_matrix=int(rng.choice([h.MATRIX_BT2020NC, h.MATRIX_YDZDX])),
+                          chroma=int(rng.choice([h.CHROMA_420, h.CHROMA_444])), resampler=0, sample=sample)
+                n = int(rng.choice([1, 2, 8, 16]))
+            mode = int(rng.integers(0, 3))
+            if mode == 1:
+                kw["stats"] = [(0, 1)] * 3
+            if mode == 2 and kind != 1:
+                kw["stats"] = [(-1, 2)] * 3
+            d = h.make_desc(w, hh, **kw)
+            host = []
+            for _ in range(n):
+                planes = _rand_planes(rng, w, hh, h.SAMPLE_F32, plant=(w * hh >= 2))
+                if rng.random() < 0.3 and w * hh >= 64:
+                    planes[1][7:19] = 0.0
+                    planes[2][23] = np.float32(-0.25)
+                    planes[0][31] = np.float32(1.5)
+                if sample == h.SAMPLE_F16:
+                    planes = [p.astype(np.float16).view(np.uint16) for p in planes]
+                host.append(planes)
+            conv = (lambda p: torch.from_numpy(np.ascontiguousarray(p).view(np.int16)).cuda()) if sample == h.SAMPLE_F16 else \
+                   (lambda p: torch.from_numpy(np.ascontiguousarray(p)).cuda())
+            dev_in = [[conv(p) for p in fr] for fr in host]
+            dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda") for _ in host]
+            torch.cuda.synchronize()
+            if it % 10 == 5 and not pending:
+                c.set_option("balance", ["0x55,1.2", "0xF0,1.1", "off", "adaptive"][int(rng.integers(0, 4))])
+            c.convert_batch_enqueue(d, dev_in, dev_out)
+            pending.append((d, host, dev_out, (it, w, hh, n, kw), dev_in))
+            if len(pending) == 2 or rng.random() < 0.4:  # finish the older one (sometimes right away, sometimes with one behind it)
+                c.batch_finish()
+                check(pending.pop(0)[:4])
+        while pending:
+            c.batch_finish()
+            check(pending.pop(0)[:4])
+    finally:
+        c.close()

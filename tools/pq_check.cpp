@@ -22,7 +22,7 @@
 #include <thread>
 #include <vector>
 
-#include "h2y_screening.h"
+#include "../hdr2yuv_amd/csrc/h2y_math.h"
 
 using namespace h2y;
 
@@ -205,36 +205,6 @@ int main(int argc, char **argv)
         printf("powf(25, y) over [0x%08x,0x%08x) step %llu: %llu floats, mismatches %llu\n", lo, hi, (unsigned long long)stride,
                (unsigned long long)total.load(), (unsigned long long)mism.load());
         return mism ? 1 : 0;
-    }
-    if (!strcmp(argv[1], "approx")) {
-        /* binary32 screening polynomial: max |approx - reference double| / value over [LO,HI) */
-        uint32_t lo = (uint32_t)strtoul(argv[2], 0, 0), hi = (uint32_t)strtoul(argv[3], 0, 0);
-        int T = argc > 4 ? atoi(argv[4]) : 8;
-        std::vector<pq_recA> A(H2Y_PQ_NREC);
-        std::vector<pq_recB> B(H2Y_PQ_NREC);
-        std::vector<pq_rec32> T32(H2Y_PQ_NREC);
-        pq_build_table(A.data(), B.data());
-        pq_build_table32(T32.data());
-        std::vector<double> worst(T, 0.0);
-        std::vector<std::thread> th;
-        uint64_t span = (uint64_t)hi - lo;
-        for (int t = 0; t < T; t++)
-            th.emplace_back([&, t]() {
-                uint64_t a = lo + span * t / T, b = lo + span * (t + 1) / T;
-                double w = 0;
-                for (uint64_t u = a; u < b; u++) {
-                    float x = bits2f((uint32_t)u), vf;
-                    double vref = ref_chain(x, &vf);
-                    double e = fabs((double)pq_approx32(x, T32.data()) - vref) / vref;
-                    if (!(e <= w)) w = e; /* NaN-propagating max */
-                }
-                worst[t] = w;
-            });
-        for (auto &x : th) x.join();
-        double w = 0;
-        for (double x : worst) if (!(x <= w)) w = x;
-        printf("approx32 over [0x%08x,0x%08x): max relative error %.4g (2^%.2f)\n", lo, hi, w, log2(w));
-        return 0;
     }
     bool slow_only = !strcmp(argv[1], "slow");
     uint32_t lo = (uint32_t)strtoul(argv[2], 0, 0), hi = (uint32_t)strtoul(argv[3], 0, 0);

@@ -19,6 +19,7 @@
 #include "../../include/hdr2yuv_hip.h"
 #include "h2y_kernels.h"
 #include "h2y_math.h"
+#include "h2y_walk.h"
 
 using namespace h2y;
 
@@ -710,7 +711,6 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         if (check) ctx->b->approx_min = approx;
         /* XCD-aware rounds and their weights; the block clocks of timed launches feed balance_update() */
         const bool xcd_layout = h2y_fused_grouped(var) && grid % (8 * groups) == 0;
-        uint32_t fast_mask = 0xFFu, chunks_a = g.chunks;
         /* Slices by XCD speed: block i of a group takes one contiguous run of every frame's 64-tile slices, as long as
          * the measured speed of its XCD says (block i of a group runs on XCD i % 8 under xcd_layout).  "off": the even
          * round-robin dealing of frame_walk. */
@@ -725,12 +725,7 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
             }
             for (int x = 0; x < 8; x++) work[x] = sp[x] / mean;
             std::vector<uint32_t> r((size_t)G + 1u);
-            double cum = 0.0;
-            const double tot = mean * (double)G;
-            for (uint32_t i = 0; i <= G; i++) {
-                r[i] = i == G ? nslices : (uint32_t)(cum / tot * (double)nslices + 0.5);
-                if (i < G) cum += sp[i % 8u];
-            }
+            slice_ranges(sp, G, nslices, r.data()); /* h2y_walk.h */
             if (ctx->b->ranges_cap < r.size()) {
                 if (ctx->b->d_ranges) HIP_TRY(ctx, hipFree(ctx->b->d_ranges));
                 if (ctx->b->h_ranges) HIP_TRY(ctx, hipHostFree(ctx->b->h_ranges));
@@ -759,8 +754,6 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         }
         fused_args a;
         a.xcd_layout = xcd_layout ? 1u : 0u;
-        a.fast_mask = fast_mask;
-        a.chunks_a = chunks_a;
         a.block_clock = clocks ? ctx->b->d_clock : nullptr;
         a.slice_ranges = d_slice_ranges;
         a.redo_count = t1 ? ctx->b->d_redo : nullptr;
@@ -1697,8 +1690,6 @@ int h2y_matrix_convert(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3
     a.chunks_per_frame = g.chunks;
     a.groups = 1;
     a.xcd_layout = 0;
-    a.fast_mask = 0xFFu;
-    a.chunks_a = g.chunks;
     a.block_clock = nullptr;
     a.slice_ranges = nullptr;
     a.table = ctx->d_table;

@@ -62,8 +62,6 @@ struct fused_args {
     uint32_t groups;          /* k_fused2 / k_fused_t1 / k_fused_lut16: the grid works as this many groups of gridDim.x / groups
                                  blocks, group g on frames g, g + groups, ... (1: every block on every frame); divides gridDim.x */
     uint32_t xcd_layout;      /* 1: gridDim.x is a multiple of 8 * groups and groups are made of whole rounds of the eight XCDs */
-    uint32_t fast_mask;       /* xcd_layout: the XCDs (bit = blockIdx.x % 8) whose blocks take the second part of every frame */
-    uint32_t chunks_a;        /* xcd_layout: chunks [0, chunks_a) of a frame go round all blocks, the rest round the fast ones */
     unsigned long long *block_clock; /* [gridDim.x][2]: start, finish (wall_clock64) of each block, or NULL; finish entries zero at launch */
     const uint32_t *slice_ranges; /* xcd_layout, loop-form kernels: [gridDim.x / groups + 1] first 64-tile slice of every block of a group
                                      (the last entry = slices per frame): block i of a group takes slices [r[i], r[i+1]) of each of the

@@ -300,11 +300,11 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS, PIPE == H2Y_PIPE_RUNTIME ? 2 : H
 }
 
 /* frame_walk (h2y_walk.h): which frames a block works on and which chunks of them -- frame groups, XCD-aware
- * layout, weighted rounds.  Glue to the launch arguments: */
+ * layout.  Glue to the launch arguments: */
 __device__ __forceinline__ void walk_init(frame_walk &fw, const fused_args &a)
 {
     walk_args wa;
-    wa.groups = a.groups; wa.xcd_layout = a.xcd_layout; wa.fast_mask = a.fast_mask; wa.chunks_a = a.chunks_a;
+    wa.groups = a.groups; wa.xcd_layout = a.xcd_layout;
     wa.chunks_per_frame = a.chunks_per_frame; wa.n_frames = a.n_frames;
     fw.init(wa, blockIdx.x, gridDim.x);
 }
@@ -327,23 +327,21 @@ __device__ __forceinline__ size_t walk_slot(const frame_walk &fw, uint32_t waves
  */
 #define H2Y_CLAIM_FRAMES 128
 struct wave_deal { /* a block's share of one frame, in slices */
-    uint32_t kA, kB, G, Gf, nA, total; /* first chunks and strides of the two parts, chunks in part A, slices in all */
-    uint32_t s0;                       /* ranged form: the block's first slice */
+    uint32_t k0, G, total; /* round robin: first chunk and stride; slices in all */
+    uint32_t s0;           /* ranged form: the block's first slice */
     bool ranged;
-    __device__ __forceinline__ void set(const frame_walk &fw, uint32_t ka, uint32_t kb, uint32_t wpb)
+    __device__ __forceinline__ void set(const frame_walk &fw, uint32_t k, uint32_t wpb)
     {
-        kA = ka; kB = kb; G = fw.G; Gf = fw.Gf;
-        nA = fw.count_a(ka);
-        total = (nA + fw.count_b(kb)) * wpb;
+        k0 = k; G = fw.G;
+        total = fw.count(k) * wpb;
         ranged = false;
         s0 = 0;
     }
     /* Ranged form (fused_args.slice_ranges): the block owns the slices [first, first + count) of every frame of its
-     * group -- one contiguous run of 64-tile slices, as long as its XCD is fast (the host cuts a frame's slices among the
-     * blocks of a group by the measured speeds of their XCDs: balance_for_launch() in h2y_api.hip). */
+     * group -- one contiguous run of 64-tile slices, as long as its XCD is fast (h2y_walk.h: slice_ranges()). */
     __device__ __forceinline__ void set_range(uint32_t first, uint32_t count)
     {
-        kA = kB = 0; G = Gf = 1; nA = 0;
+        k0 = 0; G = 1;
         s0 = first;
         total = count;
         ranged = true;
@@ -354,8 +352,7 @@ struct wave_deal { /* a block's share of one frame, in slices */
         constexpr uint32_t WPB = THREADS / WAVE;
         if (ranged) return (s0 + i) * WAVE;
         const uint32_t j = i / WPB, sub = i % WPB;
-        const uint32_t k = j < nA ? kA + j * G : kB + (j - nA) * Gf;
-        return k * THREADS + sub * WAVE;
+        return (k0 + j * G) * THREADS + sub * WAVE;
     }
 };
 /* this block's run of slices, if the launch deals by ranges: [group-relative block number] and the next entry */
@@ -481,8 +478,8 @@ __global__ __launch_bounds__(H2Y_LOOP_THREADS) void k_fused2(fused_args a)
             deal.set_range(r_first, r_count);
             deal_n.set_range(r_first, r_count);
         } else {
-            deal.set(fw, fw.kA, fw.kB, H2Y_LOOP_THREADS / WAVE);
-            deal_n.set(fw, fw.kA_n, fw.kB_n, H2Y_LOOP_THREADS / WAVE);
+            deal.set(fw, fw.k0, H2Y_LOOP_THREADS / WAVE);
+            deal_n.set(fw, fw.k0_n, H2Y_LOOP_THREADS / WAVE);
         }
         if (!have) tick = wave_claim(&s_claim[fo], s_scratch, true);
         bool more = tick < deal.total; /* (a slice carried over from the previous frame is always below the total) */
@@ -738,8 +735,8 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
             deal.set_range(r_first, r_count);
             deal_n.set_range(r_first, r_count);
         } else {
-            deal.set(fw, fw.kA, fw.kB, H2Y_T1_THREADS / WAVE);
-            deal_n.set(fw, fw.kA_n, fw.kB_n, H2Y_T1_THREADS / WAVE);
+            deal.set(fw, fw.k0, H2Y_T1_THREADS / WAVE);
+            deal_n.set(fw, fw.k0_n, H2Y_T1_THREADS / WAVE);
         }
         if (!hold) {
             tick = wave_claim(&s_claim[fo], s_scratch, true);
@@ -1023,8 +1020,8 @@ __global__ __launch_bounds__(H2Y_LOOP_THREADS) void k_fused_lut16(fused_args a)
             deal.set_range(r_first, r_count);
             deal_n.set_range(r_first, r_count);
         } else {
-            deal.set(fw, fw.kA, fw.kB, H2Y_LOOP_THREADS / WAVE);
-            deal_n.set(fw, fw.kA_n, fw.kB_n, H2Y_LOOP_THREADS / WAVE);
+            deal.set(fw, fw.k0, H2Y_LOOP_THREADS / WAVE);
+            deal_n.set(fw, fw.k0_n, H2Y_LOOP_THREADS / WAVE);
         }
         if (!have) tick = wave_claim(&s_claim[fo], s_scratch, true);
         bool more = tick < deal.total;

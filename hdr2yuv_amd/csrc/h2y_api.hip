@@ -1239,9 +1239,12 @@ int h2y_batch_finish(h2y_ctx *ctx, int *n_redone)
     ctx->last_ms = ms;
     ctx->last_launches = ctx->b->n_ev;
 #ifdef H2Y_BLOCK_TIMES
-    if (const char *e = getenv("H2Y_BLOCK_TIMES_FILE")) {
-        if (!strcmp(ctx->last_name, "k_fir_fused")) h2y_dump_ff_block_times(e);
-        else h2y_dump_block_times(e);
+    if (const char *e = getenv("H2Y_BLOCK_TIMES_FILE")) { /* one file per finished batch: <name>.<n> */
+        static int n_dump = 0;
+        char fn[512];
+        snprintf(fn, sizeof fn, "%s.%d", e, n_dump++);
+        if (!strcmp(ctx->last_name, "k_fir_fused")) h2y_dump_ff_block_times(fn);
+        else h2y_dump_block_times(fn);
     }
 #endif
     int redone = 0;

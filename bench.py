@@ -231,6 +231,18 @@ def cpu_baseline_parallel(desc_kw, resampler, frames_each=2):
             "sample": f"{cores} processes x {frames_each} frame(s), {dt:.1f} s wall including process start-up"}
 
 
+def sources_sha256():
+    """sha256 over the library's sources (kernels, shim, headers): what a counter file under profiles/ is valid for --
+    a rebuild of the same sources gives another binary (build id) but the same kernels."""
+    hsh = hashlib.sha256()
+    src = os.path.join(ROOT, "hdr2yuv_amd", "csrc")
+    for name in sorted(os.listdir(src)) + [os.path.join("..", "..", "include", "hdr2yuv_hip.h")]:
+        if name.endswith((".hip", ".h", "Makefile")):
+            with open(os.path.join(src, name), "rb") as f:
+                hsh.update(name.encode() + b"\0" + f.read())
+    return hsh.hexdigest()
+
+
 def known_md5(stem, is420, resampler):
     name = stem if not is420 else f"{stem}_{resampler}"
     with open(os.path.join(ROOT, "tests", "golden", "known_md5.json")) as f:
@@ -443,7 +455,8 @@ def main() -> int:
         "per_rank_mpixels_s": [round(v, 1) for v in main_r["per_rank"]],
         "verified": main_r["verified"],
         "verify": {"case": main_r["verify_case"], "md5": main_r["md5"], "what": "md5 of rank 0's output frame 0 after the timed loop vs tests/golden/known_md5.json"},
-        "library": {"path": os.path.relpath(lib_path, ROOT) if lib_path.startswith(ROOT) else lib_path, "sha256": lib_sha},
+        "library": {"path": os.path.relpath(lib_path, ROOT) if lib_path.startswith(ROOT) else lib_path, "sha256": lib_sha,
+                    "sources_sha256": sources_sha256()},
         "options": args.option,
     }
     traffic, traffic_source = None, None
@@ -452,11 +465,11 @@ def main() -> int:
         try:
             tj = json.load(open(tpath))
             ent = tj.get(f"{args.workload}_{args.resampler}_F{F}")
-            if ent and ent.get("library_sha256") == lib_sha:
+            if ent and not args.lib and tj.get("sources_sha256") == sources_sha256():
                 traffic = ent.get("hbm_bytes_per_launch")
-                traffic_source = f"{TRAFFIC_FILE} (rocprofv3 --pmc passes of this very library build; static, not this run)"
+                traffic_source = f"{TRAFFIC_FILE} (rocprofv3 --pmc passes over these very sources; static, not this run)"
             elif ent:
-                traffic_source = f"{TRAFFIC_FILE} holds counters of another library build: not quoted"
+                traffic_source = f"{TRAFFIC_FILE} holds counters of other sources: not quoted"
         except Exception:
             traffic = None
     out["roofline"] = roofline_of(main_r, traffic, traffic_source)

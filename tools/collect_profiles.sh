@@ -27,9 +27,13 @@ python3 - "$OUT" <<'PY'
 import hashlib, json, os, re, sys
 out = sys.argv[1]
 sha = hashlib.sha256(open("hdr2yuv_amd/libhdr2yuv_hip.so", "rb").read()).hexdigest()
+import importlib.util
+spec = importlib.util.spec_from_file_location("bench_mod", "bench.py")
+bench = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(bench)
 res = {"_how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, tools/prof.sh) on `python3 bench.py --no-extra --no-cpu-baseline ...`; "
                "per-dispatch average of the dominant kernel; FETCH_SIZE doubled (MI355X_MICROARCH.md: gfx950 reports half the bytes of wide coalesced "
-               "16-B/lane reads), both in KiB", "library_sha256": sha}
+               "16-B/lane reads), both in KiB", "library_sha256": sha, "sources_sha256": bench.sources_sha256()}
 alg = {"c2box": ("C2_box_F64", 15.0 * 3840 * 2160 * 64), "c2fir": ("C2_fir_F64", 15.0 * 3840 * 2160 * 64), "c3": ("C3_box_F64", 18.0 * 3840 * 2160 * 64),
        "c4": ("C4_box_F16", 9.0 * 7680 * 4320 * 16)}
 for name, (key, ab) in alg.items():

@@ -645,7 +645,19 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
     const size_t npix = (size_t)d->width * d->height;
     /* one launch covers at most kMaxFramesPerLaunch frames: k_fused_t1's waves draw their tiles from one LDS counter
      * per frame of their group (H2Y_CLAIM_FRAMES of them) */
-    const int step = out_kind == H2Y_OUT_444TMP ? kFirSubBatch : (n < kMaxFramesPerLaunch ? n : kMaxFramesPerLaunch);
+    /* (with frame groups the bound is per GROUP: a launch of g groups takes up to g x 128 frames -- sub_batch() below) */
+    auto sub_batch = [&](int left) -> int {
+        if (out_kind == H2Y_OUT_444TMP) return left < kFirSubBatch ? left : kFirSubBatch;
+        if (left <= kMaxFramesPerLaunch || !h2y_fused_grouped(var)) return left < kMaxFramesPerLaunch ? left : kMaxFramesPerLaunch;
+        const int gridf = grid_for(ctx, var, (uint64_t)g.chunks * left);
+        for (int ng = ctx->opt_groups; ng > 1; ng >>= 1)
+            if (gridf % ng == 0) {
+                int cand = left < kMaxFramesPerLaunch * ng ? left : kMaxFramesPerLaunch * ng;
+                cand -= cand % ng; /* whole groups; what is left over goes into the next launch */
+                return cand > kMaxFramesPerLaunch ? cand : kMaxFramesPerLaunch;
+            }
+        return kMaxFramesPerLaunch;
+    };
     /* the 4:4:4 chroma scratch of the two-pass FIR form: as many frames as a sub-batch holds, twice over when the batch
      * has more than one sub-batch (sub-batch i writes half i % 2 while the FIR pass still reads the other).  A single
      * frame (h2y_convert_frame, the CLI's ring) takes 33 MB at 4K, not the 2.1 GB of a full double sub-batch. */
@@ -658,8 +670,8 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         if (rc) return rc;
     }
     int sub = 0;
-    for (int f0 = 0; f0 < n; f0 += step, sub++) {
-        const int nf = (n - f0 < step) ? n - f0 : step;
+    for (int f0 = 0, nf = 0; f0 < n; f0 += nf, sub++) {
+        nf = sub_batch(n - f0);
         const int half = sub & 1;
         if (out_kind == H2Y_OUT_444TMP && ctx->fir_used[half]) /* scratch half still being read by an earlier FIR pass? */
             HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_fir[half], 0));
@@ -692,6 +704,7 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
                     groups = ng;
                     break;
                 }
+        if (nf / groups > kMaxFramesPerLaunch) return fail(ctx, H2Y_EINVAL, "internal: %d frames in %d groups exceed the per-group bound", nf, groups);
         int rc = ensure(ctx, ctx->b->d_partial, ctx->b->partial_cap, (size_t)nf * grid * waves * 6 * sizeof(float));
         if (rc) return rc;
         const bool t1 = var.pipe == 4 || var.pipe == 5;

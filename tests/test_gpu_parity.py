@@ -271,15 +271,20 @@ def test_long_batch_is_split_into_launches(oracle, kind):
     want = [oracle.convert_frame(od, fr) for fr in host]
     fresh = h.Context(0)
     try:
-        for rnd in range(2):
+        for rnd in range(3):
+            # the bound is 128 frames per frame GROUP of a launch: round 0 with the default groups, round 1 with
+            # one group (128 + 128 + 74), round 2 with two (256 + 74 -- more than 128 frames in one launch)
+            if rnd:
+                fresh.set_option("groups", rnd)
             dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda") for _ in host]
             torch.cuda.synchronize()
             fresh.convert_batch_enqueue(d, dev_in, dev_out)
             redone = fresh.batch_finish()
-            assert redone == 1  # frame 300 differs from what was assumed (round 0: frame 0's statistics; round 1: the hint)
+            assert redone == 1  # frame 300 differs from what was assumed (round 0: frame 0's statistics; later: the hint)
+            ms, launches = fresh.last_kernel_ms()
             if rnd == 1:
-                ms, launches = fresh.last_kernel_ms()
-                assert launches >= 3, launches  # 330 frames at no more than 128 per launch
+                assert launches >= 3, launches
+            assert launches >= 2, launches
             for f in range(n):
                 got = dev_out[f].cpu().numpy().view(np.uint16)
                 assert np.array_equal(got, want[f]), f"{kind} round {rnd} frame {f}: {np.count_nonzero(got != want[f])} samples differ"

@@ -803,6 +803,10 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
 #endif
 #pragma unroll
                     for (int col = 0; col < 4; col++) {
+#ifdef H2Y_EXP_NOCOMPUTE /* timing experiment only (wrong bytes): the loop's loads, stores and tickets alone */
+                        Y[col] = f2bits(gv[col]) >> 20; Cb[col] = f2bits(bv[col]) >> 20; Cr[col] = f2bits(rv[col]) >> 20;
+                        continue;
+#endif
 #ifdef H2Y_HALF_COMPUTE /* timing experiments only: how much of the time is arithmetic? */
                         if (row == 1) { Y[col] = o.yp0[col >> 1] >> (16 * (col & 1)) & 0xFFFFu; Cb[col] = sb[col >> 1] >> 1; Cr[col] = sr[col >> 1] >> 1; continue; }
 #endif

@@ -72,6 +72,10 @@ def parse(argv=None):
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="h2y_ctx_set_option knobs (A/B timing), e.g. fir=twopass")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (nccl = RCCL; gloo only to rehearse N > 1)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--content", default="uniform", choices=["uniform", "bars", "squared"],
+                    help="synthetic picture content (fp32 workloads): uniform = the SURVEY 8c generator (the headline; md5-checked); bars = the same "
+                         "with the top and bottom 12.8 %% of the rows exactly zero (a 2.39:1 picture letterboxed in 16:9); squared = every sample "
+                         "squared (darker).  Not md5-checked; implies --no-extra")
     ap.add_argument("--no-pipeline", action="store_true", help="finish every step before the next is enqueued (A/B against two batches in flight)")
     ap.add_argument("--rehearse", action="store_true",
                     help="CPU rehearsal of the N-rank launch: ranks rendezvous (gloo), shard the frame indices and reduce made-up counters; "
@@ -377,6 +381,8 @@ def main() -> int:
         verified, vname, got_md5 = None, None, None
         if rank == 0:
             vname, want = known_md5(stem, is420, resampler)
+            if args.content != "uniform":
+                vname, want = f"none (content {args.content})", None
             if want:
                 got_md5 = hashlib.md5(outs_t[0].cpu().numpy().tobytes()).hexdigest()
                 verified = got_md5 == want
@@ -408,6 +414,19 @@ def main() -> int:
     F = args.frames
     w, hh = desc_kw["width"], desc_kw["height"]
     frames_in = device_frames(desc_kw, frames_for_rank(world * F, rank, world))  # this rank's contiguous block of the global frame sequence
+    if args.content != "uniform":
+        if desc_kw.get("sample", 2) != 2:
+            raise SystemExit("--content applies to the fp32 workloads")
+        args.no_extra = True
+        bar = int(round(0.128 * hh))
+        for fr in frames_in:
+            for p in fr:
+                if args.content == "squared":
+                    p.mul_(p)
+                else:
+                    p[: bar * w] = 0.0
+                    p[(hh - bar) * w:] = 0.0
+                    p[bar * w + 1] = 1.0  # (the planted 1.0 of the generator sat in the first row: ceiling 1 again)
     torch.cuda.synchronize()
 
     # a plain device-to-device copy of 1 GiB on this very box (30 times): context only, it swings by +-10 % between runs
@@ -444,7 +463,7 @@ def main() -> int:
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32+f64",
-        "data": "synthetic",
+        "data": "synthetic" if args.content == "uniform" else f"synthetic ({args.content})",
         "config": {
             "workload": f"{args.workload}: {wl_name}, chroma {args.resampler}" if is420 else f"{args.workload}: {wl_name}",
             "frames_per_gpu_per_step": F,

@@ -55,7 +55,11 @@ clip_limits make_clip(int bit_depth, int full_range)
 
 const int kMaxEvents = 64;
 const double kT1DenseShare = 0.08; /* T1 costs ~1.6x more per redone tile, k_fused2 ~1.12x overall: break-even near 8 % */
-const int kT1SkipBatches = 8;
+/* A probe of the first tier on dense content is dear (letterboxed 4K, a quarter of the tiles flagged: 8.6 ms per 64-frame launch
+ * against k_fused2's 1.6), staying on the binary64 tier too long is cheap (2-10 % slower than the first tier on content that
+ * suits it): probe rarely -- after 32 batches, then 64, ... 1024. */
+const int kT1SkipBatches = 32;
+const int kT1SkipBatchesMax = 1024;
 const int kFirSubBatch = 32; /* frames per fused launch on the FIR path: every launch pays its table staging and its last redo pass */
 
 } // namespace
@@ -120,6 +124,7 @@ struct h2y_ctx {
     bool fir_used[2] = {false, false};
     void *d_table = nullptr;
     void *d_table1 = nullptr; /* binary32 first-tier records */
+    void *d_table_ext = nullptr; /* pq_build_table_ext(): the binary64 table below 2^-24, read from global memory by pq_slow() */
     void *d_tfn[H2Y_TFN_COUNT] = {}; /* the other transfer functions' tables (tfn_build_table), built when first needed */
     float *d_lut16 = nullptr; /* PQ10000_r of every half in [0,2), built on the device at creation */
     /* The first tier is slow on pictures with many exactly-zero samples (black bars: every such tile is done twice).
@@ -337,9 +342,16 @@ void t1_end_batch(h2y_ctx *ctx, const h2y_desc *d, const frame_stats *fs, int n)
     uint64_t redone = 0;
     for (int f = 0; f < n; f++) redone += fs[f].redone;
     const uint64_t tiles = (uint64_t)n * make_geom(d, 1024).tiles;
+    { /* for whoever asks h2y_last_kernel_variant(): the share of tiles the first tier passed on */
+        const size_t at = ctx->last_variant.find(" flagged=");
+        if (at != std::string::npos) ctx->last_variant.erase(at);
+        char note[48];
+        snprintf(note, sizeof note, " flagged=%.5f", tiles ? (double)redone / (double)tiles : 0.0);
+        ctx->last_variant += note;
+    }
     if ((double)redone > kT1DenseShare * (double)tiles) {
-        /* still dense at the next probe: stay away twice as long (8, 16, ... 128 batches) */
-        ctx->t1_skip_len = ctx->t1_skip_len ? (ctx->t1_skip_len < 128 ? 2 * ctx->t1_skip_len : 128) : kT1SkipBatches;
+        /* still dense at the next probe: stay away twice as long */
+        ctx->t1_skip_len = ctx->t1_skip_len ? (ctx->t1_skip_len < kT1SkipBatchesMax ? 2 * ctx->t1_skip_len : kT1SkipBatchesMax) : kT1SkipBatches;
         ctx->t1_skip = ctx->t1_skip_len;
     } else ctx->t1_skip_len = 0;
 }
@@ -446,6 +458,7 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
 {
     pix_params pp;
     derive_params(d, &pp, false);
+    pp.pq_ext = ctx->d_table_ext;
     const int out_kind = out_kind_of(d);
     t1_sens sn;
     fused_variant var = pick_variant(ctx, d, pp, out_kind, known, &sn);
@@ -1022,6 +1035,15 @@ static int ctx_init(h2y_ctx *ctx, int device)
         char *t = static_cast<char *>(ctx->d_table);
         HIP_TRY(ctx, hipMemcpy(t, A.data(), H2Y_PQ_NREC * 16, hipMemcpyHostToDevice));
         HIP_TRY(ctx, hipMemcpy(t + H2Y_PQ_NREC * 16, B.data(), H2Y_PQ_NREC * 16, hipMemcpyHostToDevice));
+        {
+            std::vector<pq_recA> XA(H2Y_PQX_NSEG);
+            std::vector<pq_recB> XB(H2Y_PQX_NSEG);
+            pq_build_table_ext(XA.data(), XB.data());
+            HIP_TRY(ctx, hipMalloc(&ctx->d_table_ext, H2Y_PQX_TABLE_BYTES));
+            char *x = static_cast<char *>(ctx->d_table_ext);
+            HIP_TRY(ctx, hipMemcpy(x, XA.data(), H2Y_PQX_NSEG * 16, hipMemcpyHostToDevice));
+            HIP_TRY(ctx, hipMemcpy(x + H2Y_PQX_NSEG * 16, XB.data(), H2Y_PQX_NSEG * 16, hipMemcpyHostToDevice));
+        }
         std::vector<pq_rec1> T1(H2Y_T1_NREC);
         pq_build_table1(T1.data());
         HIP_TRY(ctx, hipMalloc(&ctx->d_table1, H2Y_T1_NREC * sizeof(pq_rec1)));
@@ -1131,6 +1153,7 @@ void h2y_ctx_destroy(h2y_ctx *ctx)
     for (void *t : ctx->d_tfn) (void)hipFree(t);
     (void)hipFree(ctx->d_lut16);
     (void)hipFree(ctx->d_table1);
+    (void)hipFree(ctx->d_table_ext);
     (void)hipFree(ctx->d_tmp);
     (void)hipFree(ctx->d_up);
     (void)hipFree(ctx->d_in);
@@ -1676,6 +1699,7 @@ int h2y_matrix_convert(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3
     ctx->b->dev_assumed_ok = false; /* d_assumed[0] no longer holds what the last enqueued batch left there */
     pix_params pp;
     derive_params(d, &pp, true);
+    pp.pq_ext = ctx->d_table_ext;
     fused_variant var;
     var.in_kind = in_kind_of(d);
     var.out_kind = H2Y_OUT_444TMP;

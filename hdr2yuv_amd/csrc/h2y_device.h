@@ -235,9 +235,9 @@ __device__ __attribute__((noinline)) ycc pixel_careful(const pix_params *spp /* 
     uint32_t &Y = o.y, &Cb = o.cb, &Cr = o.cr;
     if (pp.convert_transfer) {
         /* convert.cpp:1024-1109: source transfer -> linear -> destination transfer, then the scale step */
-        G = pix_scale(tf_from_linear(pp.dst_tf, tf_to_linear(pp.src_tf, G)), pp.mulY, pp.addY);
-        B = pix_scale(tf_from_linear(pp.dst_tf, tf_to_linear(pp.src_tf, B)), pp.mulC, pp.addC);
-        R = pix_scale(tf_from_linear(pp.dst_tf, tf_to_linear(pp.src_tf, R)), pp.mulC, pp.addC);
+        G = pix_scale(tf_from_linear(pp.dst_tf, tf_to_linear(pp.src_tf, G), pp.pq_ext), pp.mulY, pp.addY);
+        B = pix_scale(tf_from_linear(pp.dst_tf, tf_to_linear(pp.src_tf, B), pp.pq_ext), pp.mulC, pp.addC);
+        R = pix_scale(tf_from_linear(pp.dst_tf, tf_to_linear(pp.src_tf, R), pp.pq_ext), pp.mulC, pp.addC);
     }
     bool dummy;
     pix_matrix<MODE, true>(pp, G, B, R, Y, Cb, Cr, &dummy);

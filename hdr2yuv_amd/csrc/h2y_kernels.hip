@@ -421,25 +421,26 @@ __device__ __forceinline__ void block_clock_end(const fused_args &a)
  * IEEE divisions.
  */
 template <int PIPE>
-__device__ __forceinline__ float pq_sample(const pix_params &pp, int c, float raw, const pq_recA *sA, const pq_recB *sB, bool &any_slow)
+__device__ __forceinline__ float pq_sample(const pix_params &pp, int c, float raw, const pq_recA *sA, const pq_recB *sB, bool &any_slow,
+                                           const void *const *s_ext /* LDS: pp.pq_ext, read only here */)
 {
     if (PIPE == H2Y_PIPE_NONE) return raw; /* convert.cpp:930: no transfer conversion, no normalisation, no scale step */
     const float x = norm1<PIPE>(pp, c, raw);
     bool slow;
     float v = pq_fast(x, sA, sB, &slow);
-    if (__builtin_expect(slow, 0)) v = pq_slow(x);
+    if (__builtin_expect(slow, 0)) v = pq_slow(x, *s_ext);
     any_slow |= slow;
     return pix_scale(v, c == 0 ? pp.mulY : pp.mulC, c == 0 ? pp.addY : pp.addC);
 }
 /* the same from a record already fetched (x normalised) */
-__device__ __forceinline__ float pq_sample_rec(const pix_params &pp, int c, float x, const pq_rec &rec, bool &any_slow)
+__device__ __forceinline__ float pq_sample_rec(const pix_params &pp, int c, float x, const pq_rec &rec, bool &any_slow, const void *const *s_ext)
 {
     bool sl;
     float v = pq_eval(x, rec, &sl);
     const bool zero = f2bits(x) == 0u; /* as pq_fast(): +0.0 is outside the table but its value is a constant */
     const bool slow = sl & !zero;
     v = zero ? bits2f(H2Y_PQ_AT_ZERO_BITS) : v;
-    if (__builtin_expect(slow, 0)) v = pq_slow(x);
+    if (__builtin_expect(slow, 0)) v = pq_slow(x, *s_ext);
     any_slow |= slow;
     return pix_scale(v, c == 0 ? pp.mulY : pp.mulC, c == 0 ? pp.addY : pp.addC);
 }
@@ -450,8 +451,10 @@ __global__ __launch_bounds__(H2Y_LOOP_THREADS) void k_fused2(fused_args a)
     const pq_recA *sA = s_tab;
     const pq_recB *sB = reinterpret_cast<const pq_recB *>(s_tab + (PIPE == H2Y_PIPE_NONE ? 0 : H2Y_PQ_NREC));
     __shared__ uint32_t s_claim[H2Y_CLAIM_FRAMES], s_scratch[WAVE];
+    __shared__ const void *s_ext; /* a.pp.pq_ext, for the rare pq_slow() */
     if (PIPE != H2Y_PIPE_NONE) stage_table<H2Y_LOOP_THREADS>(a.table, s_tab);
     if (threadIdx.x < H2Y_CLAIM_FRAMES) s_claim[threadIdx.x] = 0u;
+    if (threadIdx.x == 0) s_ext = a.pp.pq_ext;
     const pix_params pp = with_assumed(a.pp, a.assumed);
     __syncthreads();
 
@@ -521,9 +524,9 @@ __global__ __launch_bounds__(H2Y_LOOP_THREADS) void k_fused2(fused_args a)
                         const float xg = norm1<PIPE>(pp, 0, gv[col]), xb = norm1<PIPE>(pp, 1, bv[col]), xr = norm1<PIPE>(pp, 2, rv[col]);
                         const pq_rec cg = pq_fetch(xg, sA, sB), cb = pq_fetch(xb, sA, sB), cr = pq_fetch(xr, sA, sB);
                         __builtin_amdgcn_sched_barrier(0);
-                        g = pq_sample_rec(pp, 0, xg, cg, odd);
-                        b = pq_sample_rec(pp, 1, xb, cb, odd);
-                        r = pq_sample_rec(pp, 2, xr, cr, odd);
+                        g = pq_sample_rec(pp, 0, xg, cg, odd, &s_ext);
+                        b = pq_sample_rec(pp, 1, xb, cb, odd, &s_ext);
+                        r = pq_sample_rec(pp, 2, xr, cr, odd, &s_ext);
                     }
                     bool um;
                     pix_matrix<MODE, false>(pp, g, b, r, Y[col], Cb[col], Cr[col], &um);

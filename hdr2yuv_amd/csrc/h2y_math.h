@@ -221,10 +221,15 @@ H2Y_FN double pow_dd(double x, double y) { return dd_exp(dd_mul_d(dd_log(x), y))
  * Out-of-domain inputs follow C's pow(): negative or NaN -> NaN, +inf -> NaN
  * (inf/inf); those are outside the pinned domain anyway.
  */
-H2Y_FN_NOINLINE float pq_slow(float x)
+H2Y_FN bool pq_ext_try(float x, const void *ext, float *v); /* below, with the tables */
+H2Y_FN_NOINLINE float pq_slow(float x, const void *ext = nullptr)
 {
     if (!(x >= 0.0f) || x > 3.4028234e38f) return bits2f(0x7FC00000u);
     if (x == 0.0f) return bits2f(H2Y_PQ_AT_ZERO_BITS); /* black is common: pow(0, m1) = 0, so this is a constant */
+    /* normal floats below 2: the polynomial tier again, from the full-range table in global memory (pq_build_table_ext),
+     * before the double-double arithmetic below -- two 16-byte loads instead of ~30 us */
+    float ve;
+    if (ext && pq_ext_try(x, ext, &ve)) return ve;
     double Ln = pow_dd((double)x, H2Y_PQ_M1);
     double num = H2Y_PQ_C1 + H2Y_PQ_C2 * Ln;
     double den = 1.0 + H2Y_PQ_C3 * Ln;
@@ -361,9 +366,9 @@ H2Y_FN float tf_to_linear(int cls, float V)
     }
     return V;
 }
-H2Y_FN float tf_from_linear(int cls, float L)
+H2Y_FN float tf_from_linear(int cls, float L, const void *pq_ext = nullptr)
 {
-    if (cls == H2Y_TF_PQ) return pq_slow(L); /* PQ10000_r */
+    if (cls == H2Y_TF_PQ) return pq_slow(L, pq_ext); /* PQ10000_r */
     if (cls == H2Y_TF_RHO_GAMMA) {           /* RHO_GAMMA_r, convert.cpp:30-38: log(rho) is logf */
         double a = 1.0 + 24.0 * pow_gen((double)L, 1.0 / (double)2.4f);
         double la = (a > 0.0 && a < 1.7976931348623157e308) ? dd_log(a).hi : bits2d(0x7FF8000000000000ull);
@@ -541,11 +546,11 @@ H2Y_FN float pq_fast(float x, const pq_recA *__restrict__ A, const pq_recB *__re
  * in double-double), expand to monomials, round c0..c2 to binary64 and c3,c4
  * to binary32.  Pure IEEE double arithmetic: the same table on every host, no
  * libm involved.  A and B each hold H2Y_PQ_NREC records. */
-inline void pq_build_table(pq_recA *A, pq_recB *B)
+inline void pq_build_segments(pq_recA *A, pq_recB *B, int emin, int nseg)
 {
     const double un[5] = {-0.9510565162951535, -0.5877852522924731, 0.0, 0.5877852522924731, 0.9510565162951535};
-    for (int i = 0; i < H2Y_PQ_NSEG; i++) {
-        int e = H2Y_PQ_EMIN + i / H2Y_PQ_SEG_PER_BINADE;
+    for (int i = 0; i < nseg; i++) {
+        int e = emin + i / H2Y_PQ_SEG_PER_BINADE;
         int s = i % H2Y_PQ_SEG_PER_BINADE;
         double scale = bits2d((uint64_t)(1023 + e) << 52);
         double mid = scale * (1.0 + (s + 0.5) / H2Y_PQ_SEG_PER_BINADE); /* exact */
@@ -579,12 +584,41 @@ inline void pq_build_table(pq_recA *A, pq_recB *B)
         B[i].c3 = (float)(c[3].hi * r * r * r);
         B[i].c4 = (float)(c[4].hi * r * r * r * r);
     }
+}
+inline void pq_build_table(pq_recA *A, pq_recB *B)
+{
+    pq_build_segments(A, B, H2Y_PQ_EMIN, H2Y_PQ_NSEG);
     /* sentinel: 1 + 2^-24 is exactly half way between two floats */
     A[H2Y_PQ_NSEG].c0 = 1.0 + 0x1p-24;
     A[H2Y_PQ_NSEG].c1 = 0.0;
     B[H2Y_PQ_NSEG].c2 = 0.0;
     B[H2Y_PQ_NSEG].c3 = 0.0f;
     B[H2Y_PQ_NSEG].c4 = 0.0f;
+}
+
+/* ------------------------------------------------------------------------
+ * The same table over every NORMAL float below 2 (exponents -126 .. 0; 8128 segments, 254 KB), in global memory, read
+ * only from pq_slow(): by the samples the LDS tables do not cover -- pictures that did not pass through half floats
+ * can hold positive samples below 2^-24 -- and by the other samples of a pixel that pixel_careful() redoes as a whole.
+ * The double-double arithmetic costs ~30 us of a wave's time per sample (a 4K frame with 0.02 % of its samples below
+ * 2^-24 ran 24 % longer, the fused FIR path twice as long).  Same polynomial, same ambiguity test; subnormal inputs
+ * and ambiguous values still go to the double-double tier.  Checked against libm like the LDS table
+ * (tools/pq_check ext: every float of [2^-126, 2)).
+ * ---------------------------------------------------------------------- */
+#define H2Y_PQX_EMIN (-126)
+#define H2Y_PQX_NSEG ((1 - H2Y_PQX_EMIN) * H2Y_PQ_SEG_PER_BINADE)
+#define H2Y_PQX_SEG_BASE ((uint32_t)(127 + H2Y_PQX_EMIN) << H2Y_PQ_SEG_BITS)
+#define H2Y_PQX_TABLE_BYTES (H2Y_PQX_NSEG * 32) /* pq_recA[NSEG], then pq_recB[NSEG] */
+inline void pq_build_table_ext(pq_recA *A, pq_recB *B) { pq_build_segments(A, B, H2Y_PQX_EMIN, H2Y_PQX_NSEG); }
+H2Y_FN bool pq_ext_try(float x, const void *ext, float *v)
+{
+    const uint32_t bits = f2bits(x), idx = (bits >> H2Y_PQ_LOW_BITS) - H2Y_PQX_SEG_BASE; /* subnormal: wraps high; >= 2, negative, NaN: high */
+    if (idx >= (uint32_t)H2Y_PQX_NSEG) return false;
+    const pq_recA *A = reinterpret_cast<const pq_recA *>(ext);
+    const pq_recB *B = reinterpret_cast<const pq_recB *>(A + H2Y_PQX_NSEG);
+    const double d = pq_poly(bits, A[idx], B[idx]);
+    *v = (float)d;
+    return !pq_ambiguous(d);
 }
 
 /* ------------------------------------------------------------------------
@@ -973,6 +1007,7 @@ struct pix_params {
     /* the same limits on the UNSHIFTED value (pix_limits_finish): lo << s and (hi << s) | (2^s - 1),
      * and for the 2x2 box sum of four chroma values (s + 2) */
     uint32_t ylo_s, yhi_s, clo_s, chi_s, clo_b, chi_b;
+    const void *pq_ext;        /* pq_build_table_ext() in device memory (NULL: none): read by the careful paths only */
 };
 inline void pix_limits_finish(pix_params *pp)
 {

@@ -711,19 +711,19 @@ def test_tier_steering_on_black_frames(oracle):
     c = h.Context(0)
     try:
         names = []
-        for step in range(14):
-            planes = black if step < 11 else noise
+        for step in range(37):
+            planes = black if step < 35 else noise
             dev_in = [[torch.from_numpy(p).cuda() for p in planes] for _ in range(2)]
             dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda") for _ in range(2)]
             torch.cuda.synchronize()  # the context's stream does not wait for torch's
             c.convert_batch(d, dev_in, dev_out)
             names.append(c.last_kernel_name())
             for t in dev_out:
-                assert np.array_equal(t.cpu().numpy().view(np.uint16), want_black if step < 11 else want_noise), step
+                assert np.array_equal(t.cpu().numpy().view(np.uint16), want_black if step < 35 else want_noise), step
         assert names[0] == "k_fused_t1"              # first batch: nothing known yet
-        assert names[1:9] == ["k_fused2"] * 8        # eight batches away from the first tier
-        assert names[9] == "k_fused_t1"              # probe: still black
-        assert names[10] == "k_fused2"               # away again (for 16 batches now)
+        assert names[1:33] == ["k_fused2"] * 32      # 32 batches away from the first tier (a probe on dense content is dear)
+        assert names[33] == "k_fused_t1"             # probe: still black
+        assert names[34:] == ["k_fused2"] * 3        # away again (for 64 batches now), whatever the pictures hold
     finally:
         c.close()
 
@@ -1174,6 +1174,67 @@ def test_context_options_and_variant_names(oracle):
                 c.set_option("balance", "0xFF,1.2")  # every XCD fast is no split at all
         finally:
             c.close()
+
+
+@pytest.mark.parametrize("path", ["t1_box", "t2_box", "fir_fused", "fir_twopass", "frame_entry", "ydzdx16_444"])
+def test_samples_below_the_tables(oracle, path):
+    """Positive samples below 2^-24 (pictures that never went through half floats hold them): outside the LDS tables of both
+    fast tiers, answered by pq_slow() from the table in global memory (pq_build_table_ext) unless ambiguous or subnormal --
+    2 % of the samples here, over the whole exponent range, plus subnormals, negative tiny values and exact zeros, through
+    every kernel that can meet them."""
+    import torch
+
+    rng = np.random.default_rng(2424)
+    w, hh, n = 256, 64, 5
+    host = []
+    for k in range(n):
+        planes = _rand_planes(rng, w, hh, h.SAMPLE_F32)
+        for p in planes:
+            idx = rng.choice(p.size - 2, p.size // 50, replace=False) + 2
+            p[idx] = (10.0 ** rng.uniform(-37.9, -7.3, idx.size)).astype(np.float32)
+            sub = rng.choice(p.size - 2, 12, replace=False) + 2
+            p[sub[:4]] = np.float32(1e-40)    # subnormal
+            p[sub[4:8]] = np.float32(-1e-12)  # negative: pow() of it is NaN in the reference
+            p[sub[8:]] = 0.0
+        host.append(planes)
+    kw = dict(dst_depth=12, dst_matrix=h.MATRIX_BT2020NC, resampler=0)
+    opts = {}
+    if path == "t2_box":
+        opts["t1"] = "0"
+    elif path == "fir_fused":
+        kw.update(dst_depth=10, resampler=1)
+        opts["fir"] = "fused"
+    elif path == "fir_twopass":
+        kw.update(dst_depth=10, resampler=1)
+        opts["fir"] = "twopass"
+    elif path == "ydzdx16_444":
+        kw = dict(dst_depth=16, dst_matrix=h.MATRIX_YDZDX, chroma=h.CHROMA_444)
+    d = h.make_desc(w, hh, **kw)
+    od = _to_oracle_desc(d)
+    want = [oracle.convert_frame(od, fr) for fr in host]
+    c = h.Context(0)
+    try:
+        for name, value in opts.items():
+            c.set_option(name, value)
+        if path == "frame_entry":
+            for f in range(n):
+                assert np.array_equal(c.convert_frame(d, host[f]), want[f]), f
+            return
+        dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in host]
+        for rnd in range(2):  # round 1 runs on round 0's statistics hint
+            dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda") for _ in host]
+            torch.cuda.synchronize()
+            c.convert_batch(d, dev_in, dev_out)
+            if rnd == 0:
+                kernel, variant = c.last_kernel_name(), c.last_kernel_variant()
+                assert kernel == {"t1_box": "k_fused_t1", "t2_box": "k_fused2", "fir_fused": "k_fir_fused", "fir_twopass": "k_fused_t1",
+                                  "ydzdx16_444": "k_fused2"}[path], variant
+                assert ("+k_fir420" in variant) == (path == "fir_twopass"), variant
+            for f in range(n):
+                got = dev_out[f].cpu().numpy().view(np.uint16)
+                assert np.array_equal(got, want[f]), f"{path} round {rnd} frame {f}: {np.count_nonzero(got != want[f])} samples differ"
+    finally:
+        c.close()
 
 
 @pytest.mark.parametrize("balance", ["0x55,1.12", "0xAA,1.25", "0x0F,1.2"])

@@ -51,6 +51,19 @@ def test_out_of_table_goes_to_slow_tier(pq_check):
         assert m and int(m.group(1)) - int(m.group(2)) == (1 if lo == 0 else 0)
 
 
+def test_full_range_table_of_the_slow_tier(pq_check):
+    """pq_build_table_ext / pq_ext_try (h2y_math.h): the binary64 polynomial table over every normal float below 2, which
+    pq_slow() reads from global memory before falling back to double-double arithmetic (samples below the LDS tables'
+    2^-24; the other samples of a pixel redone as a whole).  Strided over the whole range (the exhaustive run takes 10 s on
+    eight cores: `pq_check ext 0x00800000 0x40000000 8 1`), plus every float of two binades, the subnormals' top and both
+    ends of the table (subnormals and x >= 2 must take the double-double tier)."""
+    for lo, hi, stride in (("0x00800000", "0x40000000", "509"), ("0x20000000", "0x20800000", "1"), ("0x3F000000", "0x3F800000", "1"),
+                           ("0x007F0000", "0x00810000", "1"), ("0x3FFF0000", "0x40010000", "1")):
+        r = subprocess.run([pq_check, "ext", lo, hi, "8", stride], capture_output=True, text=True)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "mismatches 0," in r.stdout, r.stdout
+
+
 def test_slow_tier_sampled(pq_check):
     rc, out = _run(pq_check, "slow", "0x3f000000", "0x3f040000", "4")
     assert rc == 0, out

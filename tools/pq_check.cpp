@@ -206,6 +206,49 @@ int main(int argc, char **argv)
                (unsigned long long)total.load(), (unsigned long long)mism.load());
         return mism ? 1 : 0;
     }
+    if (!strcmp(argv[1], "ext")) {
+        /* pq_check ext <lo> <hi> [threads] [stride]: the table below 2^-24 (pq_build_table_ext, read by pq_slow()): every
+         * float of [lo, hi) at the stride -- normal floats below 2^-24 take the table unless ambiguous, everything else
+         * the double-double tier -- against the reference chain with this libm */
+        uint32_t lo = (uint32_t)strtoul(argv[2], 0, 0), hi = (uint32_t)strtoul(argv[3], 0, 0);
+        int T = argc > 4 ? atoi(argv[4]) : 8;
+        uint64_t stride = argc > 5 ? strtoull(argv[5], 0, 0) : 1;
+        std::vector<pq_recA> X(2 * H2Y_PQX_NSEG);
+        pq_build_table_ext(X.data(), reinterpret_cast<pq_recB *>(X.data() + H2Y_PQX_NSEG));
+        std::atomic<uint64_t> mism{0}, ntab{0}, maxerr{0}, total{0};
+        std::vector<std::thread> th;
+        uint64_t span = (uint64_t)hi - lo;
+        for (int t = 0; t < T; t++)
+            th.emplace_back([&, t]() {
+                uint64_t a = lo + span * t / T, b = lo + span * (t + 1) / T;
+                a += (stride - (a - lo) % stride) % stride;
+                uint64_t mm = 0, nt = 0, me = 0, n = 0;
+                for (uint64_t u = a; u < b; u += stride, n++) {
+                    const float x = bits2f((uint32_t)u);
+                    float want, tv;
+                    const double vref = ref_chain(x, &want);
+                    const float got = pq_slow(x, X.data());
+                    if (pq_ext_try(x, X.data(), &tv)) {
+                        nt++;
+                        const uint32_t idx = ((uint32_t)u >> H2Y_PQ_LOW_BITS) - H2Y_PQX_SEG_BASE;
+                        const double v = pq_poly((uint32_t)u, X[idx], reinterpret_cast<const pq_recB *>(X.data() + H2Y_PQX_NSEG)[idx]);
+                        const int64_t d = (int64_t)(d2bits(v) - d2bits(vref));
+                        const uint64_t ad = d < 0 ? -d : d;
+                        if (ad > me) me = ad;
+                    }
+                    if (f2bits(got) != f2bits(want) && !(got != got && want != want))
+                        if (mm++ < 5) fprintf(stderr, "MISMATCH x=%a (0x%08x) got %a want %a\n", x, (uint32_t)u, got, want);
+                }
+                mism += mm; ntab += nt; total += n;
+                uint64_t cur = maxerr.load();
+                while (me > cur && !maxerr.compare_exchange_weak(cur, me)) {}
+            });
+        for (auto &x : th) x.join();
+        printf("ext range [0x%08x,0x%08x) step %llu: %llu floats, mismatches %llu, from the table %llu, max table err %llu ulp(double)\n", lo, hi,
+               (unsigned long long)stride, (unsigned long long)total.load(), (unsigned long long)mism.load(), (unsigned long long)ntab.load(),
+               (unsigned long long)maxerr.load());
+        return mism ? 1 : 0;
+    }
     bool slow_only = !strcmp(argv[1], "slow");
     uint32_t lo = (uint32_t)strtoul(argv[2], 0, 0), hi = (uint32_t)strtoul(argv[3], 0, 0);
     int T = argc > 4 ? atoi(argv[4]) : 8;

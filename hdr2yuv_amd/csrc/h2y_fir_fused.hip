@@ -171,6 +171,21 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
     asm volatile("" : "+v"(sn.a_lo), "+v"(sn.a_hi));
     if (threadIdx.x == 0) s_pp = pp;
     __syncthreads();
+    /* a pixel of three +0.0 samples (black bars): the first tier cannot answer it (zero is outside its table), so rows of
+     * them are recognised before the arithmetic (below) and given this pixel's code values, worked out once by the exact tiers */
+    __shared__ uint32_t s_black[3];
+    if (TIER == FF_TIER_T1) {
+        if (threadIdx.x == 0) {
+            const float G0 = norm1<PIPE>(pp, 0, 0.0f), B0 = norm1<PIPE>(pp, 1, 0.0f), R0 = norm1<PIPE>(pp, 2, 0.0f);
+            uint32_t y, cb, cr;
+            if (pixel_fast<MODE, PIPE>(pp, sA, sB, G0, B0, R0, y, cb, cr)) {
+                const ycc k = pixel_careful<MODE>(&s_pp, G0, B0, R0);
+                y = k.y; cb = k.cb; cr = k.cr;
+            }
+            s_black[0] = y; s_black[1] = cb; s_black[2] = cr;
+        }
+        __syncthreads();
+    }
 
     typedef in_traits<IN_KIND> IN;
     const uint32_t lane = threadIdx.x & (WAVE - 1);
@@ -241,6 +256,18 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
                     mm.add2(2, rv[0], rv[1]); mm.add2(2, rv[2], rv[3]);
                 }
                 uint32_t Y[4], Cb[4], Cr[4];
+                /* a row of zeros in every lane (letterbox bars)?  One compare per row for ordinary pictures: lane 0's first sample */
+                bool zrow = false;
+                if (TIER == FF_TIER_T1 && __builtin_expect(__builtin_amdgcn_ballot_w64(f2bits(gv[0]) != 0u) == 0, 0)) {
+                    const uint32_t z = (f2bits(gv[1]) | f2bits(gv[2]) | f2bits(gv[3])) | (f2bits(bv[0]) | f2bits(bv[1]) | f2bits(bv[2])) |
+                                       (f2bits(bv[3]) | f2bits(rv[0]) | f2bits(rv[1])) | (f2bits(rv[2]) | f2bits(rv[3]));
+                    zrow = __builtin_amdgcn_ballot_w64(z != 0u) == 0;
+                }
+                if (zrow) {
+                    const uint32_t y0 = s_black[0], cb0 = s_black[1], cr0 = s_black[2];
+#pragma unroll
+                    for (int col = 0; col < 4; col++) { Y[col] = y0; Cb[col] = cb0; Cr[col] = cr0; }
+                } else
 #pragma unroll
                 for (int col = 0; col < 4; col++) {
                     if (TIER == FF_TIER_LUT16) {

@@ -695,6 +695,21 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
         s_rc.tiles_per_frame = a.tiles_per_frame; s_rc.tiles_magic = a.tiles_magic;
     }
     __syncthreads();
+    /* a pixel of three +0.0 samples (black bars): the first tier cannot answer it (zero is outside its table), so rows of
+     * them are recognised before the arithmetic (in the tile loop) and given this pixel's code values, worked out once by
+     * the exact tiers */
+    __shared__ uint32_t s_black[3];
+    if (threadIdx.x == 0) {
+        const pq_recB *sB2 = reinterpret_cast<const pq_recB *>(s_t2 + H2Y_PQ_NREC);
+        const float G0 = norm1<PIPE>(pp, 0, 0.0f), B0 = norm1<PIPE>(pp, 1, 0.0f), R0 = norm1<PIPE>(pp, 2, 0.0f);
+        uint32_t y, cb, cr;
+        if (pixel_fast<MODE, PIPE>(pp, s_t2, sB2, G0, B0, R0, y, cb, cr)) {
+            const ycc k = pixel_careful<MODE>(&s_pp, G0, B0, R0);
+            y = k.y; cb = k.cb; cr = k.cr;
+        }
+        s_black[0] = y; s_black[1] = cb; s_black[2] = cr;
+    }
+    __syncthreads();
 
     block_clock_start(a);
     const uint32_t W = a.width, H = a.height;
@@ -804,6 +819,19 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
                     pq_rec1 ng = pq_t1_fetch(norm1<PIPE>(pp, 0, gv[0]), s_t1), nb = pq_t1_fetch(norm1<PIPE>(pp, 1, bv[0]), s_t1),
                             nr = pq_t1_fetch(norm1<PIPE>(pp, 2, rv[0]), s_t1);
 #endif
+                    /* a row of zeros in every lane (letterbox bars)?  One compare per row for ordinary pictures: each lane's
+                     * first sample.  Such rows get the black pixel's code values and are not flagged. */
+                    bool zrow = false;
+                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(f2bits(gv[0]) != 0u) == 0, 0)) {
+                        const uint32_t z = (f2bits(gv[1]) | f2bits(gv[2]) | f2bits(gv[3])) | (f2bits(bv[0]) | f2bits(bv[1]) | f2bits(bv[2])) |
+                                           (f2bits(bv[3]) | f2bits(rv[0]) | f2bits(rv[1])) | (f2bits(rv[2]) | f2bits(rv[3]));
+                        zrow = __builtin_amdgcn_ballot_w64(z != 0u) == 0;
+                    }
+                    if (zrow) {
+                        const uint32_t y0 = s_black[0], cb0 = s_black[1], cr0 = s_black[2];
+#pragma unroll
+                        for (int col = 0; col < 4; col++) { Y[col] = y0; Cb[col] = cb0; Cr[col] = cr0; }
+                    } else
 #pragma unroll
                     for (int col = 0; col < 4; col++) {
 #ifdef H2Y_EXP_NOCOMPUTE /* timing experiment only (wrong bytes): the loop's loads, stores and tickets alone */

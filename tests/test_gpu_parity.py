@@ -696,7 +696,8 @@ def test_fuzz_descriptors_against_oracle(ctx, oracle):
 
 
 def test_tier_steering_on_black_frames(oracle):
-    """Frames full of exact zeros make the first-tier kernel redo every tile; the context notices (share
+    """Exact zeros scattered through a picture (not whole rows of them: those the first tier answers itself, see
+    test_rows_of_zeros_stay_on_the_first_tier) make the first-tier kernel redo every tile; the context notices (share
     of redone tiles) and sends the next batches to the binary64-tier kernel, probing the first tier again
     later.  Bytes are the oracle's whichever kernel runs."""
     import torch
@@ -705,7 +706,9 @@ def test_tier_steering_on_black_frames(oracle):
     d = h.make_desc(w, hh, dst_depth=12, dst_matrix=h.MATRIX_BT2020NC, resampler=0, stats=[(0, 1)] * 3)
     od = _to_oracle_desc(d)
     rng = np.random.default_rng(5)
-    black = [np.zeros(w * hh, np.float32) for _ in range(3)]
+    black = [rng.uniform(0, 1, w * hh).astype(np.float32) for _ in range(3)]
+    for p in black:
+        p[rng.random(p.size) < 0.5] = 0.0  # half of the samples: every tile holds some, no row is all zero
     noise = [rng.uniform(0, 1, w * hh).astype(np.float32) for _ in range(3)]
     want_black, want_noise = oracle.convert_frame(od, black), oracle.convert_frame(od, noise)
     c = h.Context(0)
@@ -724,6 +727,50 @@ def test_tier_steering_on_black_frames(oracle):
         assert names[1:33] == ["k_fused2"] * 32      # 32 batches away from the first tier (a probe on dense content is dear)
         assert names[33] == "k_fused_t1"             # probe: still black
         assert names[34:] == ["k_fused2"] * 3        # away again (for 64 batches now), whatever the pictures hold
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("res", [0, 1])
+def test_rows_of_zeros_stay_on_the_first_tier(oracle, res):
+    """Letterbox bars: rows that are +0.0 in every lane of a wave are recognised before the first tier's arithmetic (which
+    cannot answer zero) and given the black pixel's code values; they are not flagged, so such pictures stay on k_fused_t1 /
+    k_fir_fused.  Bars of full rows, a bar ending inside a wave's row pair, a row that is zero except for one sample and one
+    with a -0.0 in it (both must take the ordinary path), all-black frames, measured and assumed statistics."""
+    import torch
+
+    rng = np.random.default_rng(91 + res)
+    w, hh, n = 512, 128, 6
+    host = []
+    for k in range(n):
+        planes = [rng.uniform(0.0, 1.0, w * hh).astype(np.float32) for _ in range(3)]
+        for c, p in enumerate(planes):
+            img = p.reshape(hh, w)
+            if k == 5:
+                img[:] = 0.0                      # an all-black frame
+            else:
+                img[: 16 + k] = 0.0               # top bar: 16..20 rows (odd heights end inside a row pair)
+                img[hh - 13:] = 0.0               # bottom bar
+                img[3, 77] = np.float32(0.25) if c == 1 else img[3, 77]   # one sample in a bar row
+                img[5, 300] = np.float32(-0.0) if c == 2 else img[5, 300]  # -0.0 is not the bit pattern the shortcut looks for
+            img[40, 1] = 1.0                      # ceiling 1 in every frame but the black one
+        host.append(planes)
+    d = h.make_desc(w, hh, dst_depth=10 if res else 12, dst_matrix=h.MATRIX_BT2020NC, resampler=res, stats=[(0, 1)] * 3)
+    od = _to_oracle_desc(d)
+    want = [oracle.convert_frame(od, fr) for fr in host]
+    dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in host]
+    c = h.Context(0)
+    try:
+        if res:
+            c.set_option("fir", "fused")  # (frames this small would take the two-pass form by themselves; dense zeros still steer away)
+        for rnd in range(3):
+            dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda") for _ in host]
+            torch.cuda.synchronize()
+            c.convert_batch(d, dev_in, dev_out)
+            assert c.last_kernel_name() == ("k_fir_fused" if res else "k_fused_t1"), (rnd, c.last_kernel_variant())  # never steered away
+            for f in range(n):
+                got = dev_out[f].cpu().numpy().view(np.uint16)
+                assert np.array_equal(got, want[f]), f"round {rnd} frame {f}: {np.count_nonzero(got != want[f])} samples differ"
     finally:
         c.close()
 

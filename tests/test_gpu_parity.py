@@ -731,6 +731,47 @@ def test_tier_steering_on_black_frames(oracle):
         c.close()
 
 
+@pytest.mark.parametrize("sample,hi", [(h.SAMPLE_F32, 1.0), (h.SAMPLE_F32, 2.6), (h.SAMPLE_F16, 2.6)])
+@pytest.mark.parametrize("res", [0, 1])
+def test_rows_of_zeros_with_measured_statistics(oracle, res, sample, hi):
+    """The same shortcut on the kernels' other forms: statistics measured by the kernel (round 0: the normalising variant
+    with the first frame's floor / ceiling assumed; ceiling 2 keeps it there), half input through the first tier."""
+    import torch
+
+    rng = np.random.default_rng(int(17 + res + 10 * hi))
+    w, hh, n = 512, 96, 5
+    host = []
+    for k in range(n):
+        planes = [rng.uniform(0.0, hi, w * hh).astype(np.float32) for _ in range(3)]
+        for p in planes:
+            img = p.reshape(hh, w)
+            img[: 12 + 2 * k] = 0.0
+            img[hh - 10:] = 0.0
+            img[40, 1] = hi
+        host.append([p.astype(np.float16).view(np.uint16) for p in planes] if sample == h.SAMPLE_F16 else planes)
+    d = h.make_desc(w, hh, sample=sample, dst_depth=10 if res else 12, dst_matrix=h.MATRIX_BT709, resampler=res)
+    od = _to_oracle_desc(d)
+    want = [oracle.convert_frame(od, fr) for fr in host]
+    conv = (lambda p: torch.from_numpy(p.view(np.int16)).cuda()) if sample == h.SAMPLE_F16 else (lambda p: torch.from_numpy(p).cuda())
+    dev_in = [[conv(p) for p in fr] for fr in host]
+    c = h.Context(0)
+    try:
+        if res:
+            c.set_option("fir", "fused")
+        names = set()
+        for rnd in range(2):
+            dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda") for _ in host]
+            torch.cuda.synchronize()
+            c.convert_batch(d, dev_in, dev_out)
+            names.add(c.last_kernel_variant().split(" ")[0])
+            for f in range(n):
+                got = dev_out[f].cpu().numpy().view(np.uint16)
+                assert np.array_equal(got, want[f]), f"round {rnd} frame {f}: {np.count_nonzero(got != want[f])} samples differ ({names})"
+        assert any(v.startswith("k_fir_fused" if res else "k_fused_t1") for v in names) or (sample == h.SAMPLE_F16 and hi == 1.0), names
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("res", [0, 1])
 def test_rows_of_zeros_stay_on_the_first_tier(oracle, res):
     """Letterbox bars: rows that are +0.0 in every lane of a wave are recognised before the first tier's arithmetic (which

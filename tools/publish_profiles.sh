@@ -7,8 +7,8 @@ cp $S/bench.json profiles/${R}_bench.json
 cp $S/traffic.json profiles/${R}_pmc_traffic.json
 for n in c2box c2fir c3 c4; do
   cp $S/summary_$n.txt profiles/${R}_${n}_pmc_summary.txt
-  f=$(ls $S/$n/trace/*/*kernel_stats.csv | head -1)
+  f=$(ls -t $S/$n/trace/*/*kernel_stats.csv | head -1)  # the newest: gpurun merges into what earlier calls left
   cp "$f" profiles/${R}_${n}_kernel_stats.csv
 done
-for f in tfbench.txt streambench.txt bench_c5_single_gpu.json; do [ -f $S/$f ] && cp $S/$f profiles/${R}_$f; done
+for f in tfbench.txt streambench.txt bench_c5_single_gpu.json content.txt; do [ -f $S/$f ] && cp $S/$f profiles/${R}_$f; done
 ls -la profiles/ | grep $R

@@ -76,6 +76,10 @@ def parse(argv=None):
                     help="synthetic picture content (fp32 workloads): uniform = the SURVEY 8c generator (the headline; md5-checked); bars = the same "
                          "with the top and bottom 12.8 %% of the rows exactly zero (a 2.39:1 picture letterboxed in 16:9); squared = every sample "
                          "squared (darker).  Not md5-checked; implies --no-extra")
+    ap.add_argument("--placement", default="separate", choices=["arena", "separate"],
+                    help="arena: the batch's input planes in one allocation back to back and its output frames in another (the .yuv's own "
+                         "layout); separate (default): one allocation per plane / frame.  Where the planes lie decides how often the kernels' streams meet in "
+                         "a DRAM bank: either way a launch's time moves by several per cent from process to process (DESIGN.md 7.2)")
     ap.add_argument("--no-pipeline", action="store_true", help="finish every step before the next is enqueued (A/B against two batches in flight)")
     ap.add_argument("--rehearse", action="store_true",
                     help="CPU rehearsal of the N-rank launch: ranks rendezvous (gloo), shard the frame indices and reduce made-up counters; "
@@ -127,7 +131,8 @@ class DeviceSynth:
         self.geo_c = ((torch.cumsum(geo, 0) & 0xFFFFFFFF) * 1013904223) & 0xFFFFFFFF  # c * sum_{j<=i} a^j
         del geo
 
-    def frame(self, width, height, k, f16):
+    def frame(self, width, height, k, f16, into=None):
+        """Frame k's three planes; `into` = three preallocated tensors (views of the batch's one allocation) to fill."""
         import torch
 
         n = width * height
@@ -135,11 +140,14 @@ class DeviceSynth:
         v = (s >> 8).to(torch.float32) * (1.0 / 16777216.0)
         planes = []
         for c in range(3):
-            p = v[c * n:(c + 1) * n].clone()
-            if f16:
-                p = p.to(torch.float16)
-            p[0], p[1] = 0.0, 1.0
-            planes.append(p.view(torch.int16) if f16 else p)
+            p = v[c * n:(c + 1) * n]
+            if into is not None:
+                q = into[c]
+                q.copy_(p)  # (converts to half where the plane is half)
+            else:
+                q = p.to(torch.float16) if f16 else p.clone()
+            q[0], q[1] = 0.0, 1.0
+            planes.append(q.view(torch.int16) if f16 else q)
         return planes
 
 
@@ -156,6 +164,7 @@ def run_steps(ctx, d, n_frames, ins, outs, steps, warmup, barrier, pipeline=True
     kms = 0.0
     redone = 0
     launches = 0
+    per_step = []
     # two batches in flight: step k+1 is queued behind step k before step k's statistics are looked at, so the
     # launches follow each other without a gap (same stream: the kernels never overlap, each one's HIP events are its own)
     for k in range(steps):
@@ -164,13 +173,16 @@ def run_steps(ctx, d, n_frames, ins, outs, steps, warmup, barrier, pipeline=True
             redone += ctx.batch_finish()
             ms, launches = ctx.last_kernel_ms()
             kms += ms
+            per_step.append(ms)
     if steps > 0 and pipeline:
         redone += ctx.batch_finish()
         ms, launches = ctx.last_kernel_ms()
         kms += ms
+        per_step.append(ms)
     torch.cuda.synchronize()
     barrier()
     t1 = time.perf_counter()
+    run_steps.last_per_step = per_step  # (diagnostics: every timed step's kernel ms)
     return t1 - t0, kms / max(steps, 1), redone, launches
 
 
@@ -353,7 +365,14 @@ def main() -> int:
         if key not in synth_cache:
             synth_cache.clear()
             synth_cache[key] = DeviceSynth(key, dev)
-        return [synth_cache[key].frame(w, hh, k, f16) for k in indices]
+        indices = list(indices)
+        if args.placement == "separate":
+            return [synth_cache[key].frame(w, hh, k, f16) for k in indices]
+        # one allocation for the batch's input planes, back to back (frame after frame, G B R): where planes lie in memory
+        # relative to each other decides how often the kernels' streams meet in a DRAM bank
+        n = w * hh
+        arena = torch.empty(len(indices) * 3 * n, dtype=torch.float16 if f16 else torch.float32, device=dev)
+        return [synth_cache[key].frame(w, hh, k, f16, into=[arena[(i * 3 + c) * n:(i * 3 + c + 1) * n] for c in range(3)]) for i, k in enumerate(indices)]
 
     def measure(wl, resampler, frames_in, F, steps, warmup):
         """One timed pass of workload `wl` over F frames per step (frames_in may hold fewer DISTINCT inputs: they repeat;
@@ -363,10 +382,15 @@ def main() -> int:
         w, hh = desc_kw["width"], desc_kw["height"]
         d = h.make_desc(**dict(desc_kw, resampler=1 if resampler == "fir" else 0))
         nb = h.frame_bytes(d)
-        outs_t = [torch.empty(nb // 2, dtype=torch.int16, device=dev) for _ in range(F)]
+        if args.placement == "separate":
+            outs_t = [torch.empty(nb // 2, dtype=torch.int16, device=dev) for _ in range(F)]
+        else:  # the batch's output frames in one allocation, back to back: the bytes of the .yuv file, in its order
+            out_arena = torch.empty(F * (nb // 2), dtype=torch.int16, device=dev)
+            outs_t = [out_arena[f * (nb // 2):(f + 1) * (nb // 2)] for f in range(F)]
         ins = (C.c_void_p * (3 * F))(*[t.data_ptr() for i in range(F) for t in frames_in[i % len(frames_in)]])
         outs = (C.c_void_p * F)(*[t.data_ptr() for t in outs_t])
         secs, kernel_ms, redone, launches = run_steps(ctx, d, F, ins, outs, steps, warmup, barrier, not args.no_pipeline)
+        per_step = list(run_steps.last_per_step)
         mine = torch.tensor([secs, float(F) * w * hh * steps], dtype=torch.float64, device=red_dev)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         if world > 1:
@@ -393,7 +417,7 @@ def main() -> int:
         return dict(workload=wl, text=wl_name, resampler=resampler if is420 else "none", is420=is420, secs=tmax, pixels=total_px, steps=steps,
                     per_rank=[float(t[1]) / float(t[0]) / 1e6 for t in allr], kernel_ms=kernel_ms, launches=launches, redone=redone,
                     kernel=kernel, variant=variant, verified=verified, verify_case=vname, md5=got_md5, alg_bytes=alg_bytes,
-                    ach_kernel=ach_kernel, ach_wall=ach_wall, w=w, h=hh, frames=F)
+                    ach_kernel=ach_kernel, ach_wall=ach_wall, w=w, h=hh, frames=F, per_step=per_step)
 
     def roofline_of(r, traffic=None, traffic_source=None):
         """Dominant kernel of the pass.  Box / 4:4:4 and the fused FIR path run ONE kernel per launch: `achieved` is its
@@ -468,6 +492,8 @@ def main() -> int:
             "workload": f"{args.workload}: {wl_name}, chroma {args.resampler}" if is420 else f"{args.workload}: {wl_name}",
             "frames_per_gpu_per_step": F,
             "frame_shard": "frame index, contiguous block per rank",
+            "placement": "input planes of a rank's batch back to back in one allocation, output frames in another" if args.placement == "arena"
+                         else "one allocation per plane / output frame",
             "resampler": args.resampler if is420 else "none",
         },
         "frames_per_s": round(value * 1e6 / (w * hh), 1),
@@ -521,12 +547,15 @@ def main() -> int:
             rf = roofline_of(r)
             others[key] = {"value": round(r["pixels"] / r["secs"] / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(r["secs"] / r["steps"] * 1e3, 4),
                            "frames_per_step": nf, "distinct_input_frames": len(fin), "steps": r["steps"], "kernel": r["kernel"], "variant": r["variant"],
-                           "frac": rf["frac"], "achieved_gbs": rf["achieved"], "timed_by": rf["timed_by"], "bytes_per_pixel": WORKLOADS[wl][1],
+                           "frac": rf["frac"], "kernel_ms_min_max": [round(min(r["per_step"]), 4), round(max(r["per_step"]), 4)] if r["per_step"] else None,
+                           "kernel_ms_steps": [round(x, 3) for x in r["per_step"]] if r["per_step"] and max(r["per_step"]) > 1.5 * min(r["per_step"]) else None,
+                           "frames_redone": r["redone"], "achieved_gbs": rf["achieved"], "timed_by": rf["timed_by"], "bytes_per_pixel": WORKLOADS[wl][1],
                            "verified": r["verified"], "verify_case": r["verify_case"], "workload": r["text"] + (f", chroma {res}" if r["is420"] else "")}
             failed = failed or r["verified"] is False
             if fin is not frames_in:
                 del fin
-                torch.cuda.empty_cache()
+                # (no torch.cuda.empty_cache() here: returning gigabytes to the driver in the middle of the run was followed, one
+                # run in eight, by a single 12-18 ms launch in the NEXT pass -- the card has 288 GB, the blocks stay cached)
         out["others"] = others
         if is420 and args.resampler == "box" and f"{args.workload}_fir" in others:  # round-1 field names, kept
             out["fir_value"] = others[f"{args.workload}_fir"]["value"]

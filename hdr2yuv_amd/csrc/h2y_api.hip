@@ -141,12 +141,13 @@ struct h2y_ctx {
     bool cur_skip_t1 = false;
     /* h2y_ctx_set_option(): tuning / test knobs, per context (nothing is read from the environment) */
     bool opt_t1 = true;        /* "t1": binary32 first tier on */
-    int opt_groups = 8;        /* "groups": at most this many frame groups (power of two; 1 = off) */
+    int opt_groups = 0;        /* "groups": at most this many frame groups (power of two; 1 = off); 0 = by the frame's size (groups_cap()) */
     bool opt_cols8 = true;     /* "cols8": 8-column tiles for half input where the planes allow */
     int opt_bal_mode = 0;      /* "balance": 0 adaptive, 1 off, 2 fixed */
     uint32_t opt_bal_mask = 0xFFu;
     double opt_bal_rho = 1.0;
     int opt_fir = 0;           /* "fir": 0 auto, 1 two-pass (4:4:4 scratch + k_fir420), 2 fused single pass where it applies */
+    bool opt_stagger = true;   /* "stagger": the frame groups start at different points of their blocks' runs */
     uint16_t *d_tmp = nullptr;
     size_t tmp_cap = 0;
     uint16_t *d_up = nullptr; /* h2y_inverse_420(): the two upsampled chroma planes */
@@ -318,6 +319,23 @@ geom make_geom(const h2y_desc *d, int threads, int cols = 4 /* columns of a thre
     g.tiles = g.wq * (uint32_t)((d->height + 1) / 2);
     g.chunks = (g.tiles + threads - 1) / threads;
     return g;
+}
+
+/* Frame groups of a launch (frame_walk in h2y_kernels.hip), unless the caller set a number: as few as leave every block
+ * kMinSlicesPerBlock 64-tile slices of a frame -- a 4K frame on 256 blocks: two groups, 1080p: eight, 8K: one.  Few, because
+ * with g groups g frames are read and written at equal offsets at any moment, and whether those streams meet in the same DRAM
+ * banks depends on where the frames happen to lie: eight groups ran the same 64 x 4K launch in 1.42 ... 1.72 ms from one set of
+ * buffers to the next, two in 1.42 ... 1.51, one in 1.44 ... 1.49 (tools/layoutbench.py).  Not fewer, because a block pays for
+ * every frame it visits (its waves' tickets, statistics records, the run-in of its prefetch): 1080p at one group runs at 0.47 of
+ * the bandwidth it reaches at eight (0.61). */
+const int kMinSlicesPerBlock = 100;
+int groups_cap(const h2y_ctx *ctx, uint32_t tiles_per_frame, int grid)
+{
+    if (ctx->opt_groups) return ctx->opt_groups;
+    const uint64_t slices = (tiles_per_frame + 63u) / 64u;
+    int ng = 1;
+    while (ng < 8 && slices * (uint64_t)ng < (uint64_t)kMinSlicesPerBlock * (uint64_t)grid) ng *= 2;
+    return ng;
 }
 
 int grid_for(const h2y_ctx *ctx, const fused_variant &v, uint64_t total_chunks)
@@ -663,7 +681,7 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         if (out_kind == H2Y_OUT_444TMP) return left < kFirSubBatch ? left : kFirSubBatch;
         if (left <= kMaxFramesPerLaunch || !h2y_fused_grouped(var)) return left < kMaxFramesPerLaunch ? left : kMaxFramesPerLaunch;
         const int gridf = grid_for(ctx, var, (uint64_t)g.chunks * left);
-        for (int ng = ctx->opt_groups; ng > 1; ng >>= 1)
+        for (int ng = groups_cap(ctx, g.tiles, gridf); ng > 1; ng >>= 1)
             if (gridf % ng == 0) {
                 int cand = left < kMaxFramesPerLaunch * ng ? left : kMaxFramesPerLaunch * ng;
                 cand -= cand % ng; /* whole groups; what is left over goes into the next launch */
@@ -709,10 +727,10 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         }
         const int grid = grid_for(ctx, var, (uint64_t)g.chunks * nf);
         const int waves = h2y_fused_threads(var) / 64; /* the fused kernels leave one min/max record per wave */
-        /* frame groups (frame_walk in h2y_kernels.hip): as many as divide both the batch and the grid, up to 8 */
+        /* frame groups (frame_walk in h2y_kernels.hip): as many as divide both the batch and the grid, up to groups_cap() */
         int groups = 1;
         if (h2y_fused_grouped(var))
-            for (int ng = ctx->opt_groups; ng > 1; ng >>= 1)
+            for (int ng = groups_cap(ctx, g.tiles, grid); ng > 1; ng >>= 1)
                 if (nf % ng == 0 && grid % ng == 0) {
                     groups = ng;
                     break;
@@ -782,6 +800,7 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         a.xcd_layout = xcd_layout ? 1u : 0u;
         a.block_clock = clocks ? ctx->b->d_clock : nullptr;
         a.slice_ranges = d_slice_ranges;
+        a.stagger = ctx->opt_stagger ? 1u : 0u;
         a.redo_count = t1 ? ctx->b->d_redo : nullptr;
         a.low_flag = approx ? ctx->b->d_low : nullptr;
         a.frames = ctx->b->d_frames + ctx->slot_base + f0;
@@ -1085,10 +1104,11 @@ int h2y_ctx_create(int device, h2y_ctx **out)
 
 /* Tuning and test knobs, per context.  Nothing in this library reads the environment.
  *   "t1"      "0" | "1"                 binary32 first tier off / on (default on)
- *   "groups"  "1" .. "64"               at most this many frame groups (rounded down to a power of two; 1 = off)
+ *   "groups"  "0" | "1" .. "64"         at most this many frame groups (rounded down to a power of two; 1 = off); "0": by the frame's size (default)
  *   "cols8"   "0" | "1"                 8-column thread tiles for half input (default on)
  *   "balance" "adaptive" | "off" | "<xcd mask>,<ratio>"   weighted rounds across XCDs (default adaptive)
- *   "fir"     "auto" | "twopass" | "fused"   how the FIR resampler runs (default auto) */
+ *   "fir"     "auto" | "twopass" | "fused"   how the FIR resampler runs (default auto)
+ *   "stagger" "0" | "1"                 frame groups start at different points of their blocks' slice runs (default on) */
 int h2y_ctx_set_option(h2y_ctx *ctx, const char *name, const char *value)
 {
     if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
@@ -1096,11 +1116,12 @@ int h2y_ctx_set_option(h2y_ctx *ctx, const char *name, const char *value)
     if ((ctx->q_count > 0) || ctx->streaming) return fail(ctx, H2Y_EINVAL, "a batch is pending or a stream is open");
     if (!strcmp(name, "t1")) ctx->opt_t1 = value[0] != '0';
     else if (!strcmp(name, "cols8")) ctx->opt_cols8 = value[0] != '0';
+    else if (!strcmp(name, "stagger")) ctx->opt_stagger = value[0] != '0';
     else if (!strcmp(name, "groups")) {
         int v = atoi(value), p = 1;
-        if (v < 1) return fail(ctx, H2Y_EINVAL, "groups must be >= 1");
+        if (v < 0) return fail(ctx, H2Y_EINVAL, "groups must be >= 0");
         while (2 * p <= v && p < 64) p *= 2;
-        ctx->opt_groups = p;
+        ctx->opt_groups = v ? p : 0;
     } else if (!strcmp(name, "balance")) {
         if (!strcmp(value, "adaptive")) ctx->opt_bal_mode = 0;
         else if (!strcmp(value, "off")) ctx->opt_bal_mode = 1;
@@ -1732,6 +1753,7 @@ int h2y_matrix_convert(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3
     a.xcd_layout = 0;
     a.block_clock = nullptr;
     a.slice_ranges = nullptr;
+    a.stagger = 0u;
     a.table = ctx->d_table;
     a.table_src = a.table_dst = nullptr; /* (a generic transfer pair takes the careful tier in this stage entry) */
     a.lut16 = ctx->d_lut16;

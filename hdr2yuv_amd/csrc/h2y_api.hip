@@ -147,7 +147,6 @@ struct h2y_ctx {
     uint32_t opt_bal_mask = 0xFFu;
     double opt_bal_rho = 1.0;
     int opt_fir = 0;           /* "fir": 0 auto, 1 two-pass (4:4:4 scratch + k_fir420), 2 fused single pass where it applies */
-    bool opt_stagger = true;   /* "stagger": the frame groups start at different points of their blocks' runs */
     uint16_t *d_tmp = nullptr;
     size_t tmp_cap = 0;
     uint16_t *d_up = nullptr; /* h2y_inverse_420(): the two upsampled chroma planes */
@@ -800,7 +799,6 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         a.xcd_layout = xcd_layout ? 1u : 0u;
         a.block_clock = clocks ? ctx->b->d_clock : nullptr;
         a.slice_ranges = d_slice_ranges;
-        a.stagger = ctx->opt_stagger ? 1u : 0u;
         a.redo_count = t1 ? ctx->b->d_redo : nullptr;
         a.low_flag = approx ? ctx->b->d_low : nullptr;
         a.frames = ctx->b->d_frames + ctx->slot_base + f0;
@@ -1107,8 +1105,7 @@ int h2y_ctx_create(int device, h2y_ctx **out)
  *   "groups"  "0" | "1" .. "64"         at most this many frame groups (rounded down to a power of two; 1 = off); "0": by the frame's size (default)
  *   "cols8"   "0" | "1"                 8-column thread tiles for half input (default on)
  *   "balance" "adaptive" | "off" | "<xcd mask>,<ratio>"   weighted rounds across XCDs (default adaptive)
- *   "fir"     "auto" | "twopass" | "fused"   how the FIR resampler runs (default auto)
- *   "stagger" "0" | "1"                 frame groups start at different points of their blocks' slice runs (default on) */
+ *   "fir"     "auto" | "twopass" | "fused"   how the FIR resampler runs (default auto) */
 int h2y_ctx_set_option(h2y_ctx *ctx, const char *name, const char *value)
 {
     if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
@@ -1116,7 +1113,6 @@ int h2y_ctx_set_option(h2y_ctx *ctx, const char *name, const char *value)
     if ((ctx->q_count > 0) || ctx->streaming) return fail(ctx, H2Y_EINVAL, "a batch is pending or a stream is open");
     if (!strcmp(name, "t1")) ctx->opt_t1 = value[0] != '0';
     else if (!strcmp(name, "cols8")) ctx->opt_cols8 = value[0] != '0';
-    else if (!strcmp(name, "stagger")) ctx->opt_stagger = value[0] != '0';
     else if (!strcmp(name, "groups")) {
         int v = atoi(value), p = 1;
         if (v < 0) return fail(ctx, H2Y_EINVAL, "groups must be >= 0");
@@ -1753,7 +1749,6 @@ int h2y_matrix_convert(h2y_ctx *ctx, const h2y_desc *d, const void *const d_in[3
     a.xcd_layout = 0;
     a.block_clock = nullptr;
     a.slice_ranges = nullptr;
-    a.stagger = 0u;
     a.table = ctx->d_table;
     a.table_src = a.table_dst = nullptr; /* (a generic transfer pair takes the careful tier in this stage entry) */
     a.lut16 = ctx->d_lut16;

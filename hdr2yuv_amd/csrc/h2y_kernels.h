@@ -66,7 +66,6 @@ struct fused_args {
     const uint32_t *slice_ranges; /* xcd_layout, loop-form kernels: [gridDim.x / groups + 1] first 64-tile slice of every block of a group
                                      (the last entry = slices per frame): block i of a group takes slices [r[i], r[i+1]) of each of the
                                      group's frames; NULL = the round-robin dealing of frame_walk */
-    uint32_t stagger;         /* 1: group g's blocks start g / groups of the way into their runs and go round (wave_deal::set_range) */
     const void *table;        /* pq_recA[NREC] then pq_recB[NREC] */
     const void *table_src, *table_dst; /* k_fused, generic transfer pair (pp.convert_transfer == 2): the two stages' tables in the same
                                           format (tfn_build_table), or NULL for a stage that is the identity */

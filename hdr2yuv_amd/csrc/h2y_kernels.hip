@@ -329,7 +329,6 @@ __device__ __forceinline__ size_t walk_slot(const frame_walk &fw, uint32_t waves
 struct wave_deal { /* a block's share of one frame, in slices */
     uint32_t k0, G, total; /* round robin: first chunk and stride; slices in all */
     uint32_t s0;           /* ranged form: the block's first slice */
-    uint32_t phase;        /* ranged form: the slice of the run the block starts with (it goes round: see set_range) */
     bool ranged;
     __device__ __forceinline__ void set(const frame_walk &fw, uint32_t k, uint32_t wpb)
     {
@@ -337,44 +336,32 @@ struct wave_deal { /* a block's share of one frame, in slices */
         total = fw.count(k) * wpb;
         ranged = false;
         s0 = 0;
-        phase = 0;
     }
     /* Ranged form (fused_args.slice_ranges): the block owns the slices [first, first + count) of every frame of its
      * group -- one contiguous run of 64-tile slices, as long as its XCD is fast (h2y_walk.h: slice_ranges()). */
-    /* The block walks its run cyclically from slice `ph` on: the groups' blocks of equal number own the same run of
-     * their frames and move through it at the same pace, i.e. up to eight frames would be read and written at equal
-     * offsets at any moment -- whether that hurts depends on where the frames happen to lie in memory (same DRAM banks,
-     * other rows: 1.44 ... 1.72 ms for the same launch, tools/layoutbench2.py) --, so every group starts at another
-     * eighth of the run. */
-    __device__ __forceinline__ void set_range(uint32_t first, uint32_t count, uint32_t ph)
+    __device__ __forceinline__ void set_range(uint32_t first, uint32_t count)
     {
         k0 = 0; G = 1;
         s0 = first;
         total = count;
-        phase = ph;
         ranged = true;
     }
     /* first tile of slice i (WPB slices of 64 tiles per chunk of THREADS tiles) */
     template <int THREADS> __device__ __forceinline__ uint32_t tile0(uint32_t i) const
     {
         constexpr uint32_t WPB = THREADS / WAVE;
-        if (ranged) {
-            const uint32_t j = i + phase; /* i < total, phase < total */
-            return (s0 + (j >= total ? j - total : j)) * WAVE;
-        }
+        if (ranged) return (s0 + i) * WAVE;
         const uint32_t j = i / WPB, sub = i % WPB;
         return (k0 + j * G) * THREADS + sub * WAVE;
     }
 };
 /* this block's run of slices, if the launch deals by ranges: [group-relative block number] and the next entry */
-/* (call it right after walk_init(): fw.f is still the block's group) */
-__device__ __forceinline__ bool block_range(const fused_args &a, const frame_walk &fw, uint32_t &first, uint32_t &count, uint32_t &phase)
+__device__ __forceinline__ bool block_range(const fused_args &a, const frame_walk &fw, uint32_t &first, uint32_t &count)
 {
-    first = count = phase = 0;
+    first = count = 0;
     if (!a.slice_ranges) return false;
     first = __builtin_amdgcn_readfirstlane(a.slice_ranges[fw.bi]);
     count = __builtin_amdgcn_readfirstlane(a.slice_ranges[fw.bi + 1u]) - first;
-    if (a.stagger) phase = __builtin_amdgcn_readfirstlane((uint32_t)fw.f * count / fw.NG);
     return true;
 }
 /* draw a number: lane 0 adds to the counter, the other lanes to scratch words of their own (no branch) */
@@ -481,8 +468,8 @@ __global__ __launch_bounds__(H2Y_LOOP_THREADS) void k_fused2(fused_args a)
     frame_walk fw;
     uint32_t fo = 0, tick = 0; /* waves take their tiles by ticket: see wave_deal */
     walk_init(fw, a);
-    uint32_t r_first, r_count, r_phase;
-    const bool ranged = block_range(a, fw, r_first, r_count, r_phase);
+    uint32_t r_first, r_count;
+    const bool ranged = block_range(a, fw, r_first, r_count);
     for (; fw.f < a.n_frames; fw.advance(), fo++) {
         const int f = fw.f;
         const frame_io io = uniform_io(a.frames + f);
@@ -491,8 +478,8 @@ __global__ __launch_bounds__(H2Y_LOOP_THREADS) void k_fused2(fused_args a)
         mm.reset();
         wave_deal deal, deal_n;
         if (ranged) {
-            deal.set_range(r_first, r_count, r_phase);
-            deal_n.set_range(r_first, r_count, r_phase);
+            deal.set_range(r_first, r_count);
+            deal_n.set_range(r_first, r_count);
         } else {
             deal.set(fw, fw.k0, H2Y_LOOP_THREADS / WAVE);
             deal_n.set(fw, fw.k0_n, H2Y_LOOP_THREADS / WAVE);
@@ -751,8 +738,8 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
     uint32_t tick = 0; /* the slice in hand, if hold: of the frame the loop is at (or about to enter) */
     bool hold = false; /* (have implies hold: v is tick's tile; a redo pass drops the data, not the slice) */
     walk_init(fw, a);
-    uint32_t r_first, r_count, r_phase;
-    const bool ranged = block_range(a, fw, r_first, r_count, r_phase);
+    uint32_t r_first, r_count;
+    const bool ranged = block_range(a, fw, r_first, r_count);
     for (; fw.f < a.n_frames; fw.advance(), fo++) {
         const int f = fw.f;
         const frame_io io = uniform_io(a.frames + f);
@@ -763,8 +750,8 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
         uint32_t flagged_f = 0; /* tiles of this frame this wave sent to the list (the host steers by their share) */
         wave_deal deal, deal_n;
         if (ranged) {
-            deal.set_range(r_first, r_count, r_phase);
-            deal_n.set_range(r_first, r_count, r_phase);
+            deal.set_range(r_first, r_count);
+            deal_n.set_range(r_first, r_count);
         } else {
             deal.set(fw, fw.k0, H2Y_T1_THREADS / WAVE);
             deal_n.set(fw, fw.k0_n, H2Y_T1_THREADS / WAVE);
@@ -1050,8 +1037,8 @@ __global__ __launch_bounds__(H2Y_LOOP_THREADS) void k_fused_lut16(fused_args a)
     frame_walk fw;
     uint32_t fo = 0, tick = 0; /* waves take their tiles by ticket: see wave_deal */
     walk_init(fw, a);
-    uint32_t r_first, r_count, r_phase;
-    const bool ranged = block_range(a, fw, r_first, r_count, r_phase);
+    uint32_t r_first, r_count;
+    const bool ranged = block_range(a, fw, r_first, r_count);
     for (; fw.f < a.n_frames; fw.advance(), fo++) {
         const int f = fw.f;
         const frame_io io = uniform_io(a.frames + f);
@@ -1065,8 +1052,8 @@ __global__ __launch_bounds__(H2Y_LOOP_THREADS) void k_fused_lut16(fused_args a)
         }
         wave_deal deal, deal_n;
         if (ranged) {
-            deal.set_range(r_first, r_count, r_phase);
-            deal_n.set_range(r_first, r_count, r_phase);
+            deal.set_range(r_first, r_count);
+            deal_n.set_range(r_first, r_count);
         } else {
             deal.set(fw, fw.k0, H2Y_LOOP_THREADS / WAVE);
             deal_n.set(fw, fw.k0_n, H2Y_LOOP_THREADS / WAVE);

@@ -53,7 +53,6 @@ def main():
         arrs[name] = (a, b)
     torch.cuda.synchronize()
     res = {k: [] for k in layouts}
-    ctx.set_option("stagger", 0)
     for grp in (8, 4, 2, 1, 8):  # frame groups: how many frames the card works on at once
         ctx.set_option("groups", grp)
         for name, (a, b) in arrs.items():

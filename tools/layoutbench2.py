@@ -29,11 +29,7 @@ def main():
     ctx = h.Context(0)
     cases = []
     stag = [None]
-    if len(sys.argv) > 2 and sys.argv[2] == "stagger":  # staggered group starts off / on over good and bad placements
-        stag = [0, 1]
-        for pad in (0, 4096, 65536, 131072, 262144, 376832, 1114112, 69632):
-            cases.append((pad, pad if pad != 376832 else 282624, 0, 8))
-    elif len(sys.argv) > 2 and sys.argv[2] == "groups":  # the frame groups' part in it: a bad and a good placement at 1, 2, 4, 8 groups
+    if len(sys.argv) > 2 and sys.argv[2] == "groups":  # the frame groups' part in it: a bad and a good placement at 1, 2, 4, 8 groups
         for grp in (8, 4, 2, 1):
             for pad in (65536, 262144, 0, 376832):
                 cases.append((pad, pad if pad != 376832 else 282624, 0, grp))
@@ -65,8 +61,6 @@ def main():
         b = (C.c_void_p * F)(*[t.data_ptr() for t in lo])
         torch.cuda.synchronize()
         for st in stag:
-            if st is not None:
-                ctx.set_option("stagger", st)
             for _ in range(6):
                 ctx.convert_batch_enqueue_raw(d, F, a, b)
                 ctx.batch_finish()
@@ -76,7 +70,7 @@ def main():
                 ctx.batch_finish()
                 tot += ctx.last_kernel_ms()[0]
             results.append(((pi, po, base, grp, st), tot / 15))
-            print(f"pad_in {pi:8d} pad_out {po:8d} base {base:8d} groups {grp} stagger {st}  {tot / 15:.4f} ms  ({ctx.last_kernel_variant()})", flush=True)
+            print(f"pad_in {pi:8d} pad_out {po:8d} base {base:8d} groups {grp}  {tot / 15:.4f} ms  ({ctx.last_kernel_variant()})", flush=True)
     results.sort(key=lambda r: r[1])
     print("best:", results[:5])
     print("worst:", results[-5:])

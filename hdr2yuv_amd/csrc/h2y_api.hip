@@ -147,6 +147,7 @@ struct h2y_ctx {
     uint32_t opt_bal_mask = 0xFFu;
     double opt_bal_rho = 1.0;
     int opt_fir = 0;           /* "fir": 0 auto, 1 two-pass (4:4:4 scratch + k_fir420), 2 fused single pass where it applies */
+    int opt_fir_sync = 2;      /* "firsync": k_fir_fused's blocks meet at a barrier every so many steps (power of two; 0 = never) */
     uint16_t *d_tmp = nullptr;
     size_t tmp_cap = 0;
     uint16_t *d_up = nullptr; /* h2y_inverse_420(): the two upsampled chroma planes */
@@ -497,7 +498,7 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
          * costs six recomputed row pairs).  "auto" keeps short batches, which cannot fill the chip that way, on the
          * two-pass form. */
         const uint32_t wq = (uint32_t)d->width / 4u, h2 = (uint32_t)d->height / 2u;
-        const uint32_t ns = (wq + 59u) / 60u, gw = (uint32_t)ctx->n_cu * 16u;
+        const uint32_t ns = (wq + H2Y_FF_OWN_LANES - 1u) / H2Y_FF_OWN_LANES, gw = (uint32_t)ctx->n_cu * 16u;
         const uint32_t max_seg = h2 / 64u > 0u ? h2 / 64u : 1u;
         uint32_t want = (gw + (uint32_t)n * ns - 1u) / ((uint32_t)n * ns);
         if (want > max_seg) want = max_seg;
@@ -543,6 +544,7 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
             fa.seg_rows = seg_rows;
             fa.units_per_frame = upf;
             fa.total_units = (uint32_t)units;
+            fa.sync_mask = ctx->opt_fir_sync > 0 ? (uint32_t)ctx->opt_fir_sync - 1u : ~0u;
             fa.table = ctx->d_table;
             fa.table1 = ctx->d_table1;
             fa.lut16 = ctx->d_lut16;
@@ -1105,7 +1107,8 @@ int h2y_ctx_create(int device, h2y_ctx **out)
  *   "groups"  "0" | "1" .. "64"         at most this many frame groups (rounded down to a power of two; 1 = off); "0": by the frame's size (default)
  *   "cols8"   "0" | "1"                 8-column thread tiles for half input (default on)
  *   "balance" "adaptive" | "off" | "<xcd mask>,<ratio>"   weighted rounds across XCDs (default adaptive)
- *   "fir"     "auto" | "twopass" | "fused"   how the FIR resampler runs (default auto) */
+ *   "fir"     "auto" | "twopass" | "fused"   how the FIR resampler runs (default auto)
+ *   "firsync" "0" | "1" .. "1024"       k_fir_fused: the waves of a block meet at a barrier every so many steps (power of two; 0 = never; default 2) */
 int h2y_ctx_set_option(h2y_ctx *ctx, const char *name, const char *value)
 {
     if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
@@ -1113,7 +1116,12 @@ int h2y_ctx_set_option(h2y_ctx *ctx, const char *name, const char *value)
     if ((ctx->q_count > 0) || ctx->streaming) return fail(ctx, H2Y_EINVAL, "a batch is pending or a stream is open");
     if (!strcmp(name, "t1")) ctx->opt_t1 = value[0] != '0';
     else if (!strcmp(name, "cols8")) ctx->opt_cols8 = value[0] != '0';
-    else if (!strcmp(name, "groups")) {
+    else if (!strcmp(name, "firsync")) {
+        int v = atoi(value), p = 1;
+        if (v < 0) return fail(ctx, H2Y_EINVAL, "firsync must be >= 0");
+        while (2 * p <= v && p < 1024) p *= 2;
+        ctx->opt_fir_sync = v ? p : 0;
+    } else if (!strcmp(name, "groups")) {
         int v = atoi(value), p = 1;
         if (v < 0) return fail(ctx, H2Y_EINVAL, "groups must be >= 0");
         while (2 * p <= v && p < 64) p *= 2;

@@ -43,7 +43,8 @@
 #ifndef FF_BUFFER_STORE
 #define FF_BUFFER_STORE 1 /* 1: chroma through range-checked buffer stores (lanes without a column are dropped by the hardware) */
 #endif
-#define FF_OWN_LANES 60 /* lanes 2 .. 61 own chroma: 240 picture columns per strip */
+#define FF_OWN_LANES H2Y_FF_OWN_LANES /* lanes 2 .. 61 own chroma: 240 picture columns per strip (h2y_kernels.h) */
+#define FF_HALO ((64 - FF_OWN_LANES) / 2) /* lanes on either side that only feed the horizontal taps */
 
 struct ff_rows { /* one row pair of the lane's four columns, three planes */
     float g0[4], b0[4], r0[4], g1[4], b1[4], r1[4];
@@ -210,9 +211,9 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
             j1 = rw >> 16;
         }
         const uint32_t s_begin = j0 >= 3u ? j0 - 3u : 0u, s_end = j1 + 2u;          /* steps: row pairs s_begin .. s_end (those >= H2 are virtual) */
-        const int32_t qxu = (int32_t)(FF_OWN_LANES * strip + lane) - 2;             /* this lane's quad column, before clamping */
+        const int32_t qxu = (int32_t)(FF_OWN_LANES * strip + lane) - FF_HALO;       /* this lane's quad column, before clamping */
         const uint32_t qx = (uint32_t)min(max(qxu, 0), (int32_t)WQ - 1);
-        const bool own = lane >= 2u && lane < 2u + FF_OWN_LANES && qxu < (int32_t)WQ;
+        const bool own = lane >= (uint32_t)FF_HALO && lane < (uint32_t)FF_HALO + FF_OWN_LANES && qxu < (int32_t)WQ;
 #if FF_BUFFER_STORE
         const uint32_t qx_store = own ? qx : 0x20000000u; /* times four: past any frame, short of wrapping */
         /* the frame's output as a raw buffer: stores beyond its last byte are dropped by the hardware's range check */
@@ -239,6 +240,11 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
         for (int j = 0; j < 4; j++) asm volatile("" ::"v"(v.g0[j]), "v"(v.b0[j]), "v"(v.r0[j]), "v"(v.g1[j]), "v"(v.b1[j]), "v"(v.r1[j]));
 
         for (uint32_t s = s_begin; s <= s_end; s++) {
+            /* The block's sixteen waves are the sixteen strips of one band of rows: kept in step, they read a row of the
+             * picture at about the same time -- one DRAM page after the other instead of sixteen places at once (4K x 64
+             * frames: 1.90-1.95 ms per launch without, 1.74 every second step -- tools/firsyncbench.sh).  Waves whose units differ in length, or that
+             * have none left, just meet less often: a barrier only waits for the waves still running. */
+            if (((s - s_begin) & a.sync_mask) == 0u) __builtin_amdgcn_s_barrier();
             const uint32_t q0n = 2u * (s + 1u < H2 - 1u ? s + 1u : H2 - 1u) * WQ + qx; /* the next step's rows (the last rows again once the picture ends) */
             uint32_t yp[2][2], n_cb[2][2], n_cr[2][2]; /* new 4:2:2 values: [row][column 4L / 4L+2] */
 #pragma unroll
@@ -270,6 +276,10 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
                 } else
 #pragma unroll
                 for (int col = 0; col < 4; col++) {
+#ifdef H2Y_EXP_NOCOMPUTE /* timing experiment only (wrong bytes): the step's loads, FIR stages and stores without the pixel arithmetic */
+                    Y[col] = f2bits(gv[col]) >> 21; Cb[col] = f2bits(bv[col]) >> 21; Cr[col] = f2bits(rv[col]) >> 21;
+                    continue;
+#endif
                     if (TIER == FF_TIER_LUT16) {
                         const uint32_t hg = half_bits_of(gv[col]), hb = half_bits_of(bv[col]), hr = half_bits_of(rv[col]);
                         const float lg = s_lut[hg & (H2Y_LUT16_N - 1)], lb = s_lut[hb & (H2Y_LUT16_N - 1)], lr = s_lut[hr & (H2Y_LUT16_N - 1)];
@@ -318,8 +328,12 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
                 }
                 yp[row][0] = pix_yuv_clamp<true>(pp, Y[0], false) | (pix_yuv_clamp<true>(pp, Y[1], false) << 16);
                 yp[row][1] = pix_yuv_clamp<true>(pp, Y[2], false) | (pix_yuv_clamp<true>(pp, Y[3], false) << 16);
+#if defined(H2Y_EXP_NOCOMPUTE) && H2Y_EXP_NOCOMPUTE >= 2 /* ... nor the FIR stages: the access pattern alone */
+                n_cb[row][0] = Cb[0]; n_cb[row][1] = Cb[2]; n_cr[row][0] = Cr[0]; n_cr[row][1] = Cr[2];
+#else
                 ff_hstage(Cb, e, maxcv, n_cb[row][0], n_cb[row][1]);
                 ff_hstage(Cr, e, maxcv, n_cr[row][0], n_cr[row][1]);
+#endif
                 if (row == 0) { /* row 0 of the next step, into the registers just read for the last time */
                     IN::load4q(io.in[0], q0n, v.g0);
                     IN::load4q(io.in[1], q0n, v.b0);
@@ -346,8 +360,12 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
             }
             /* chroma row j = s - 3 from rows 2j-5 .. 2j+6 = history + the new row 2s.  Before the history is whole
              * (j < j0) the value is not yet that row's: it goes to row j0, which this lane overwrites in order */
+#if defined(H2Y_EXP_NOCOMPUTE) && H2Y_EXP_NOCOMPUTE >= 2
+            const uint32_t ocb = n_cb[0][0] | (n_cb[1][1] << 16), ocr = n_cr[0][0] | (n_cr[1][1] << 16);
+#else
             const uint32_t ocb = hb[0].out(n_cb[0][0], clo, chi) | (hb[1].out(n_cb[0][1], clo, chi) << 16);
             const uint32_t ocr = hr[0].out(n_cr[0][0], clo, chi) | (hr[1].out(n_cr[0][1], clo, chi) << 16);
+#endif
             const uint32_t jj = (s >= j0 + 3u) ? s - 3u : j0;
             /* dword index in a chroma plane: two samples per quad column.  Lanes that own no chroma column of this
              * strip carry an index far beyond the frame: the buffer store drops them (no branch, no select) */

@@ -151,6 +151,7 @@ struct firf_args {
                                  (frame, strip) column land on XCDs of both halves of the card and of both parities */
     uint32_t units_per_frame; /* n_seg * n_strips */
     uint32_t total_units;     /* n_frames * units_per_frame */
+    uint32_t sync_mask;       /* the block's waves meet at a barrier every sync_mask + 1 steps (a power of two); ~0u: never */
     const void *table, *table1;
     const float *lut16;       /* FF_TIER_LUT16: PQ of every half in [0, 2) */
     h2y::t1_sens sn;
@@ -169,6 +170,11 @@ struct up_args { /* k_up444: one or two chroma planes, (width/2 x height/2) -> (
     float fmin, fmax;            /* (float) of minCV / maxCV, convert.cpp:1932-1934 */
 };
 
+/* k_fir_fused: lanes of a wave that own chroma columns (the others, half on either side, only feed the horizontal taps):
+ * a strip is 4 x this many picture columns */
+#ifndef H2Y_FF_OWN_LANES
+#define H2Y_FF_OWN_LANES 60
+#endif
 #ifdef H2Y_BLOCK_TIMES
 void h2y_dump_block_times(const char *path); /* timing experiments only */
 void h2y_dump_ff_block_times(const char *path);

@@ -58,6 +58,7 @@ const double kT1DenseShare = 0.08; /* T1 costs ~1.6x more per redone tile, k_fus
 /* A probe of the first tier on dense content is dear (letterboxed 4K, a quarter of the tiles flagged: 8.6 ms per 64-frame launch
  * against k_fused2's 1.6), staying on the binary64 tier too long is cheap (2-10 % slower than the first tier on content that
  * suits it): probe rarely -- after 32 batches, then 64, ... 1024. */
+const double kFirSyncMaxFlagged = 0.001; /* k_fir_fused: tiles-of-eight share of unsettled pixels above which its waves are left out of step */
 const int kT1SkipBatches = 32;
 const int kT1SkipBatchesMax = 1024;
 const int kFirSubBatch = 32; /* frames per fused launch on the FIR path: every launch pays its table staging and its last redo pass */
@@ -147,7 +148,9 @@ struct h2y_ctx {
     uint32_t opt_bal_mask = 0xFFu;
     double opt_bal_rho = 1.0;
     int opt_fir = 0;           /* "fir": 0 auto, 1 two-pass (4:4:4 scratch + k_fir420), 2 fused single pass where it applies */
-    int opt_fir_sync = 2;      /* "firsync": k_fir_fused's blocks meet at a barrier every so many steps (power of two; 0 = never) */
+    int opt_fir_sync = -1;     /* "firsync": k_fir_fused's blocks meet at a barrier every so many steps (power of two; 0 = never);
+                                  -1 = by the pictures: every second step, never while the first tier passes many pixels on */
+    double fir_flag_share = 0.0; /* share of the last k_fir_fused batch's pixels (in tiles of eight) the first tier could not settle */
     uint16_t *d_tmp = nullptr;
     size_t tmp_cap = 0;
     uint16_t *d_up = nullptr; /* h2y_inverse_420(): the two upsampled chroma planes */
@@ -360,6 +363,7 @@ void t1_end_batch(h2y_ctx *ctx, const h2y_desc *d, const frame_stats *fs, int n)
     uint64_t redone = 0;
     for (int f = 0; f < n; f++) redone += fs[f].redone;
     const uint64_t tiles = (uint64_t)n * make_geom(d, 1024).tiles;
+    if (!strcmp(ctx->last_name, "k_fir_fused")) ctx->fir_flag_share = tiles ? (double)redone / (double)tiles : 0.0;
     { /* for whoever asks h2y_last_kernel_variant(): the share of tiles the first tier passed on */
         const size_t at = ctx->last_variant.find(" flagged=");
         if (at != std::string::npos) ctx->last_variant.erase(at);
@@ -544,7 +548,11 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
             fa.seg_rows = seg_rows;
             fa.units_per_frame = upf;
             fa.total_units = (uint32_t)units;
-            fa.sync_mask = ctx->opt_fir_sync > 0 ? (uint32_t)ctx->opt_fir_sync - 1u : ~0u;
+            /* In step (k_fir_fused, "In step"): every second step -- unless the pictures keep sending pixels to the exact tiers
+             * (each such pixel holds its wave for a microsecond, and in step all sixteen wait with it: a picture with 0.02 % of
+             * its samples below the tables ran in 2.75 ms in step, 2.37 out of step; the usual picture 1.74 and 1.93) */
+            const int fsync = ctx->opt_fir_sync >= 0 ? ctx->opt_fir_sync : (ctx->fir_flag_share > kFirSyncMaxFlagged ? 0 : 2);
+            fa.sync_mask = fsync > 0 ? (uint32_t)fsync - 1u : ~0u;
             fa.table = ctx->d_table;
             fa.table1 = ctx->d_table1;
             fa.lut16 = ctx->d_lut16;
@@ -1108,7 +1116,7 @@ int h2y_ctx_create(int device, h2y_ctx **out)
  *   "cols8"   "0" | "1"                 8-column thread tiles for half input (default on)
  *   "balance" "adaptive" | "off" | "<xcd mask>,<ratio>"   weighted rounds across XCDs (default adaptive)
  *   "fir"     "auto" | "twopass" | "fused"   how the FIR resampler runs (default auto)
- *   "firsync" "0" | "1" .. "1024"       k_fir_fused: the waves of a block meet at a barrier every so many steps (power of two; 0 = never; default 2) */
+ *   "firsync" "0" | "1" .. "1024"       k_fir_fused: the waves of a block meet at a barrier every so many steps (power of two; 0 = never; default "auto": 2, or 0 while many pixels go to the exact tiers) */
 int h2y_ctx_set_option(h2y_ctx *ctx, const char *name, const char *value)
 {
     if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
@@ -1118,9 +1126,10 @@ int h2y_ctx_set_option(h2y_ctx *ctx, const char *name, const char *value)
     else if (!strcmp(name, "cols8")) ctx->opt_cols8 = value[0] != '0';
     else if (!strcmp(name, "firsync")) {
         int v = atoi(value), p = 1;
-        if (v < 0) return fail(ctx, H2Y_EINVAL, "firsync must be >= 0");
+        if (!strcmp(value, "auto")) v = -1;
+        else if (v < 0) return fail(ctx, H2Y_EINVAL, "firsync must be >= 0 or \"auto\"");
         while (2 * p <= v && p < 1024) p *= 2;
-        ctx->opt_fir_sync = v ? p : 0;
+        ctx->opt_fir_sync = v > 0 ? p : v;
     } else if (!strcmp(name, "groups")) {
         int v = atoi(value), p = 1;
         if (v < 0) return fail(ctx, H2Y_EINVAL, "groups must be >= 0");

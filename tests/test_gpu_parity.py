@@ -1325,6 +1325,40 @@ def test_samples_below_the_tables(oracle, path):
         c.close()
 
 
+@pytest.mark.parametrize("firsync", ["0", "1", "2", "8", "auto"])
+def test_fir_fused_waves_in_step(oracle, firsync):
+    """k_fir_fused keeps the sixteen waves of a block in step with a barrier every few steps (`firsync`).  The waves do not
+    depend on each other, so the bytes cannot change; what must hold is that nothing hangs when the waves of a block have
+    units of different length or none at all: widths whose strips do not fill a block (8, 3, 17 strips: a block then holds
+    units of two or more frames / segments), rows cut unevenly by fixed XCD weights, more waves than units."""
+    import torch
+
+    rng = np.random.default_rng(31)
+    c = h.Context(0)
+    try:
+        c.set_option("fir", "fused")
+        c.set_option("firsync", firsync)
+        c.set_option("balance", "0x55,1.2")
+        for w, hh, n in ((1920, 270, 3), (720, 130, 5), (4080, 66, 2), (3840, 128, 1)):
+            host = [_rand_planes(rng, w, hh, h.SAMPLE_F32) for _ in range(n)]
+            d = h.make_desc(w, hh, dst_depth=10, dst_matrix=h.MATRIX_BT709, resampler=1)
+            od = _to_oracle_desc(d)
+            dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in host]
+            for rnd in range(2):
+                dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda") for _ in host]
+                torch.cuda.synchronize()
+                c.convert_batch(d, dev_in, dev_out)
+                assert c.last_kernel_name() == "k_fir_fused", c.last_kernel_variant()
+                for f in range(n):
+                    got = dev_out[f].cpu().numpy().view(np.uint16)
+                    want = oracle.convert_frame(od, host[f])
+                    assert np.array_equal(got, want), (w, hh, rnd, f, int(np.count_nonzero(got != want)))
+        with pytest.raises(h.H2YError):
+            c.set_option("firsync", "-3")
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("balance", ["0x55,1.12", "0xAA,1.25", "0x0F,1.2"])
 def test_fir_fused_rows_by_xcd_speed(oracle, balance):
     """k_fir_fused cuts every (frame, strip) column into its segments in proportion to the speeds of the XCDs its units run

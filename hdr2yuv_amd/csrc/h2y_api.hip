@@ -54,6 +54,7 @@ clip_limits make_clip(int bit_depth, int full_range)
 }
 
 const int kMaxEvents = 64;
+const size_t kRangeWords = 1025; /* a table of slice ranges: up to 1024 blocks of a group + 1 */
 const double kT1DenseShare = 0.08; /* T1 costs ~1.6x more per redone tile, k_fused2 ~1.12x overall: break-even near 8 % */
 /* A probe of the first tier on dense content is dear (letterboxed 4K, a quarter of the tiles flagged: 8.6 ms per 64-frame launch
  * against k_fused2's 1.6), staying on the binary64 tier too long is cheap (2-10 % slower than the first tier on content that
@@ -85,9 +86,12 @@ struct batch_state {
     int bal_slot = 0;                         /* the eight run times travel in the frame_stats entry after the batch's last */
     bool bal_pending = false;                 /* h_fstats[bal_slot] will hold the times of a launch dealt with bal_work */
     double bal_work[8] = {1, 1, 1, 1, 1, 1, 1, 1}; /* relative work a block of XCD x had in that launch */
-    uint32_t *d_ranges = nullptr, *h_ranges = nullptr; /* fused_args.slice_ranges: [blocks of a group + 1] */
-    size_t ranges_cap = 0;
-    std::vector<uint32_t> dev_ranges;         /* what d_ranges holds */
+    /* fused_args.slice_ranges ([blocks of a group + 1]): two tables in pinned host memory that the kernels read in place (a
+     * block reads two words of it, once) -- no copy command between two launches.  Two, because the launches of one batch may
+     * need different tables (the last one, when it holds fewer frames) while the earlier ones have not run yet. */
+    uint32_t *h_ranges = nullptr, *hd_ranges = nullptr; /* host and device address of the same 2 x kRangeWords words */
+    std::vector<uint32_t> range_slot[2];      /* what the two tables hold */
+    bool slot_busy[2] = {false, false};       /* a launch of the batch being queued reads it */
     /* k_fir_fused: the rows of every unit (frame, segment, strip), cut by XCD speed */
     uint32_t *d_unit_rows = nullptr, *h_unit_rows = nullptr;
     size_t unit_rows_cap = 0;                 /* in units */
@@ -779,22 +783,28 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
             for (int x = 0; x < 8; x++) work[x] = sp[x] / mean;
             std::vector<uint32_t> r((size_t)G + 1u);
             slice_ranges(sp, G, nslices, r.data()); /* h2y_walk.h */
-            if (ctx->b->ranges_cap < r.size()) {
-                if (ctx->b->d_ranges) HIP_TRY(ctx, hipFree(ctx->b->d_ranges));
-                if (ctx->b->h_ranges) HIP_TRY(ctx, hipHostFree(ctx->b->h_ranges));
-                ctx->b->d_ranges = ctx->b->h_ranges = nullptr;
-                ctx->b->ranges_cap = 0;
-                ctx->b->dev_ranges.clear();
-                HIP_TRY(ctx, hipMalloc((void **)&ctx->b->d_ranges, 1025 * sizeof(uint32_t)));
-                HIP_TRY(ctx, hipHostMalloc((void **)&ctx->b->h_ranges, 1025 * sizeof(uint32_t), hipHostMallocDefault));
-                ctx->b->ranges_cap = 1025;
+            if (!ctx->b->h_ranges) {
+                HIP_TRY(ctx, hipHostMalloc((void **)&ctx->b->h_ranges, 2 * kRangeWords * sizeof(uint32_t), hipHostMallocMapped));
+                HIP_TRY(ctx, hipHostGetDevicePointer((void **)&ctx->b->hd_ranges, ctx->b->h_ranges, 0));
             }
-            if (ctx->b->dev_ranges != r) {
-                memcpy(ctx->b->h_ranges, r.data(), r.size() * sizeof(uint32_t));
-                HIP_TRY(ctx, hipMemcpyAsync(ctx->b->d_ranges, ctx->b->h_ranges, r.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-                ctx->b->dev_ranges = r;
+            if (r.size() > kRangeWords) return fail(ctx, H2Y_EINVAL, "internal: %zu slice ranges", r.size());
+            if (sub == 0) ctx->b->slot_busy[0] = ctx->b->slot_busy[1] = false; /* the batch that last used this state has finished */
+            int slot = -1;
+            for (int k = 0; k < 2 && slot < 0; k++)
+                if (ctx->b->range_slot[k] == r) slot = k;
+            if (slot < 0) {
+                for (int k = 0; k < 2 && slot < 0; k++)
+                    if (!ctx->b->slot_busy[k]) slot = k;
+                if (slot < 0) { /* a third table within one batch: wait for the launches that read the other two */
+                    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+                    ctx->b->slot_busy[0] = ctx->b->slot_busy[1] = false;
+                    slot = 0;
+                }
+                memcpy(ctx->b->h_ranges + (size_t)slot * kRangeWords, r.data(), r.size() * sizeof(uint32_t));
+                ctx->b->range_slot[slot] = r;
             }
-            d_slice_ranges = ctx->b->d_ranges;
+            ctx->b->slot_busy[slot] = true;
+            d_slice_ranges = ctx->b->hd_ranges + (size_t)slot * kRangeWords;
         }
         const bool clocks = xcd_layout && time_it;
         if (clocks) {
@@ -1174,7 +1184,6 @@ void h2y_ctx_destroy(h2y_ctx *ctx)
         (void)hipFree(b.d_redo);
         (void)hipFree(b.d_low);
         (void)hipFree(b.d_clock);
-        (void)hipFree(b.d_ranges);
         (void)hipHostFree(b.h_ranges);
         (void)hipFree(b.d_unit_rows);
         (void)hipHostFree(b.h_unit_rows);

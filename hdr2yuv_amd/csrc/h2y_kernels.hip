@@ -1253,9 +1253,10 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS) void k_stats(stats_args a)
  *   F32/F16: (int)min, (int)max                     common.cpp:135-136
  *   U16    : min, max with the ceiling snap         common.cpp:91-106
  */
-__global__ __launch_bounds__(256) void k_stats_final(final_args a)
+#define H2Y_FINAL_THREADS 1024 /* one block per frame over up to 4096 per-wave records: 15 us with 256 threads, the gap between two launches */
+__global__ __launch_bounds__(H2Y_FINAL_THREADS) void k_stats_final(final_args a)
 {
-    __shared__ float s_red[4 * 6];
+    __shared__ float s_red[(H2Y_FINAL_THREADS / WAVE) * 6];
     const int f = blockIdx.x;
     const float *p = a.partial + (size_t)f * a.nblk * 6;
     mm6 mm;
@@ -1278,7 +1279,7 @@ __global__ __launch_bounds__(256) void k_stats_final(final_args a)
         __syncthreads();
         if (threadIdx.x == 0) out->redone = s_cnt;
     } else if (threadIdx.x == 0) out->redone = 0;
-    block_store_mm<4>(mm, s_red, out->mm);
+    block_store_mm<H2Y_FINAL_THREADS / WAVE>(mm, s_red, out->mm);
     if (threadIdx.x == 0) {
         int bad = 0;
         for (int c = 0; c < 3; c++) {
@@ -1663,7 +1664,7 @@ hipError_t h2y_launch_stats(int in_kind, int grid, hipStream_t st, const stats_a
 
 hipError_t h2y_launch_stats_final(int n_frames, hipStream_t st, const final_args &a)
 {
-    hipLaunchKernelGGL(k_stats_final, dim3(n_frames), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_stats_final, dim3(n_frames), dim3(H2Y_FINAL_THREADS), 0, st, a);
     return hipGetLastError();
 }
 

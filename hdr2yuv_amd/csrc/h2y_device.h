@@ -100,6 +100,8 @@ __device__ __forceinline__ void block_store_mm(mm6 &m, float *smem /* NWAVES*6 *
             v = is_max ? fmaxf(v, o) : fminf(v, o);
         }
         dst[threadIdx.x] = v;
+        smem[threadIdx.x] = v; /* (its own column's first entry, read above: after the barrier smem[0..5] is the block's result --
+                                  dst may be host memory, not to be read back) */
     }
     __syncthreads();
 }

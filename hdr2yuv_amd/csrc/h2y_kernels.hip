@@ -1257,33 +1257,57 @@ __global__ __launch_bounds__(H2Y_FUSED_THREADS) void k_stats(stats_args a)
 __global__ __launch_bounds__(H2Y_FINAL_THREADS) void k_stats_final(final_args a)
 {
     __shared__ float s_red[(H2Y_FINAL_THREADS / WAVE) * 6];
+    __shared__ uint32_t s_cnt;
+    __shared__ int s_start[1024], s_finish[1024], s_min[8]; /* block clocks (grids hold at most 1024 blocks: four per CU) */
     const int f = blockIdx.x;
     const float *p = a.partial + (size_t)f * a.nblk * 6;
+    frame_stats *out = a.out + f;
+    /* Everything this block reads from memory is asked for here, at once: the kernel is a chain of short steps, and every
+     * step that began with a load of its own cost another round trip -- 15 us in all, which is time between two launches. */
     mm6 mm;
     mm.reset();
-    for (int i = threadIdx.x; i < a.nblk; i += blockDim.x)
+    uint32_t cnt = 0;
+    for (int i = threadIdx.x; i < a.nblk; i += blockDim.x) {
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             /* plain min/max: partials are never NaN (fminf/fmaxf dropped them) */
             mm.lo[c] = fminf(mm.lo[c], p[i * 6 + 2 * c]);
             mm.hi[c] = fmaxf(mm.hi[c], p[i * 6 + 2 * c + 1]);
         }
-    frame_stats *out = a.out + f;
-    if (a.redo_count) { /* total of the per-wave counts: a handful of atomics in LDS-free form would do; this is one block per frame */
-        __shared__ uint32_t s_cnt;
-        if (threadIdx.x == 0) s_cnt = 0;
-        __syncthreads();
-        uint32_t c = 0;
-        for (int i = threadIdx.x; i < a.nblk; i += blockDim.x) c += a.redo_count[(size_t)f * a.nblk + i];
-        atomicAdd(&s_cnt, c);
-        __syncthreads();
-        if (threadIdx.x == 0) out->redone = s_cnt;
-    } else if (threadIdx.x == 0) out->redone = 0;
-    block_store_mm<H2Y_FINAL_THREADS / WAVE>(mm, s_red, out->mm);
+        if (a.redo_count) cnt += a.redo_count[(size_t)f * a.nblk + i];
+    }
+    int as_floor[3] = {0, 0, 0}, as_ceil[3] = {0, 0, 0};
+    uint32_t low = 0;
     if (threadIdx.x == 0) {
+        if (a.check)
+            for (int c = 0; c < 3; c++) { as_floor[c] = a.assumed->floor_[c]; as_ceil[c] = a.assumed->ceil_[c]; }
+        if (a.low_flag) low = a.low_flag[f];
+    }
+    const bool clocks = a.block_clock && f == 0;
+    const int nb = min(a.grid, 1024);
+    if (clocks) {
+        const unsigned long long ref = a.block_clock[0];
+        for (int b = (int)threadIdx.x; b < a.grid; b += (int)blockDim.x) {
+            if (b < nb) {
+                s_start[b] = (int)(long long)(a.block_clock[2 * b] - ref);
+                s_finish[b] = (int)(long long)(a.block_clock[2 * b + 1] - ref);
+            }
+            a.block_clock[2 * b + 1] = 0ull; /* ready for the next launch's atomicMax */
+        }
+    }
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    if (a.redo_count) { /* one add per wave */
+#pragma unroll
+        for (int o = WAVE / 2; o > 0; o >>= 1) cnt += (uint32_t)__shfl_xor((int)cnt, o, WAVE);
+        if ((threadIdx.x & (WAVE - 1)) == 0) atomicAdd(&s_cnt, cnt);
+    }
+    block_store_mm<H2Y_FINAL_THREADS / WAVE>(mm, s_red, out->mm); /* (two barriers inside: s_cnt is complete after it) */
+    if (threadIdx.x == 0) {
+        out->redone = a.redo_count ? s_cnt : 0u;
         int bad = 0;
         for (int c = 0; c < 3; c++) {
-            float lo = out->mm[2 * c], hi = out->mm[2 * c + 1];
+            float lo = s_red[2 * c], hi = s_red[2 * c + 1]; /* (out is pinned host memory: not to be read back) */
             int fl, ce;
             if (a.is_u16) {
                 fl = (int)lo;
@@ -1302,37 +1326,40 @@ __global__ __launch_bounds__(H2Y_FINAL_THREADS) void k_stats_final(final_args a)
             }
             out->floor_[c] = fl;
             out->ceil_[c] = ce;
-            if (a.check && (fl != a.assumed->floor_[c] || ce != a.assumed->ceil_[c])) bad = 1;
+            if (a.check && (fl != as_floor[c] || ce != as_ceil[c])) bad = 1;
             if (a.publish && f == 0) {
                 a.publish->floor_[c] = fl;
                 a.publish->ceil_[c] = ce;
             }
         }
         if (a.low_flag) { /* k_fused_t1 with the subsampled minimum: a sample <= -1 somewhere makes floor_ unknown */
-            if (a.low_flag[f]) bad = 1;
+            if (low) bad = 1;
             a.low_flag[f] = 0u; /* ready for the next launch */
         }
         out->mismatch = bad;
     }
-    /* the launch's block clocks, per XCD (block b ran on XCD b % 8): the host balances the next launch by them */
-    if (a.block_clock && f == 0) {
-        /* 32-bit ticks relative to block 0's start (the starts lie within microseconds, a launch lasts
-         * milliseconds: 100 MHz ticks fit easily): native LDS atomics */
-        __shared__ int s_t0;
-        __shared__ uint32_t s_sum[8], s_n[8];
-        const unsigned long long ref = a.block_clock[0];
-        if (threadIdx.x == 0) s_t0 = 0;
-        if (threadIdx.x < 8) { s_sum[threadIdx.x] = 0u; s_n[threadIdx.x] = 0u; }
-        __syncthreads();
-        for (int b = threadIdx.x; b < a.grid; b += blockDim.x) atomicMin(&s_t0, (int)(long long)(a.block_clock[2 * b] - ref));
-        __syncthreads();
-        for (int b = threadIdx.x; b < a.grid; b += blockDim.x) {
-            atomicAdd(&s_sum[b & 7], (uint32_t)((long long)(a.block_clock[2 * b + 1] - ref) - s_t0));
-            atomicAdd(&s_n[b & 7], 1u);
-            a.block_clock[2 * b + 1] = 0ull; /* ready for the next launch's atomicMax */
+    /* the launch's block clocks, per XCD (block b ran on XCD b % 8): the host balances the next launch by them.
+     * 32-bit ticks relative to the earliest start (the starts lie within microseconds, a launch lasts milliseconds: 100 MHz
+     * ticks fit easily); eight threads, one per XCD, add up their own blocks' from LDS. */
+    if (clocks) {
+        const int x = (int)threadIdx.x;
+        if (x < 8) {
+            int mn = 0; /* block 0 itself */
+            for (int b = x; b < nb; b += 8) mn = min(mn, s_start[b]);
+            s_min[x] = mn;
         }
         __syncthreads();
-        if (threadIdx.x < 8) a.xcd_time[threadIdx.x] = s_n[threadIdx.x] ? (float)s_sum[threadIdx.x] / (float)s_n[threadIdx.x] * 0.01f : 0.f; /* 100 MHz ticks -> us */
+        if (x < 8) {
+            int t0 = s_min[0];
+#pragma unroll
+            for (int k = 1; k < 8; k++) t0 = min(t0, s_min[k]);
+            uint32_t sum = 0u, n = 0u;
+            for (int b = x; b < nb; b += 8) {
+                sum += (uint32_t)(s_finish[b] - t0);
+                n++;
+            }
+            a.xcd_time[x] = n ? (float)sum / (float)n * 0.01f : 0.f; /* 100 MHz ticks -> us */
+        }
     }
 }
 

@@ -46,9 +46,21 @@
 #define FF_OWN_LANES H2Y_FF_OWN_LANES /* lanes 2 .. 61 own chroma: 240 picture columns per strip (h2y_kernels.h) */
 #define FF_HALO ((64 - FF_OWN_LANES) / 2) /* lanes on either side that only feed the horizontal taps */
 
-struct ff_rows { /* one row pair of the lane's four columns, three planes */
-    float g0[4], b0[4], r0[4], g1[4], b1[4], r1[4];
-};
+/* one row pair of the lane's four columns, three planes: as floats, or -- FF_TIER_LUT16, whose table is indexed by the
+ * half's bits -- as the halves they were loaded as, two to a register (widening them only to narrow them again cost 48
+ * conversions a step, 7 % of that tier's instructions) */
+template <bool RAW> struct ff_rows;
+template <> struct ff_rows<false> { float g0[4], b0[4], r0[4], g1[4], b1[4], r1[4]; };
+template <> struct ff_rows<true> { uint32_t g0[2], b0[2], r0[2], g1[2], b1[2], r1[2]; };
+template <int IN_KIND> __device__ __forceinline__ void ff_load(const void *p, uint32_t q, float (&d)[4]) { in_traits<IN_KIND>::load4q(p, q, d); }
+template <int IN_KIND> __device__ __forceinline__ void ff_load(const void *p, uint32_t q, uint32_t (&d)[2])
+{
+    const u32x2 t = gload_nt<u32x2>(p, q); /* four halves */
+    d[0] = t.x; d[1] = t.y;
+}
+__device__ __forceinline__ uint32_t ff_pk_min_h(uint32_t a, uint32_t b) { uint32_t r; asm("v_pk_min_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ uint32_t ff_pk_max_h(uint32_t a, uint32_t b) { uint32_t r; asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float ff_half_to_float(uint32_t h) { return (float)__builtin_bit_cast(_Float16, (uint16_t)h); }
 
 /* lane L gets lane L-1's / L+1's value (DPP wave shifts; what arrives in lane 0 resp. 63 is never used) */
 __device__ __forceinline__ uint32_t from_lane_below(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138 /* wave_shr:1 */, 0xF, 0xF, true); }
@@ -135,7 +147,6 @@ struct ff_hist {
  *                  by construction); a pixel with a sample outside it, or whose division guard fires, takes the careful tier */
 #define FF_TIER_T1 0
 #define FF_TIER_LUT16 1
-__device__ __forceinline__ uint32_t half_bits_of(float v) { return (uint32_t)__builtin_bit_cast(uint16_t, (_Float16)v); } /* exact: v was a half */
 
 #ifdef H2Y_BLOCK_TIMES /* timing experiments only: when does each block start and finish? (tools/blocktimes.py) */
 __device__ unsigned long long g_ff_block_times[2 * 1024];
@@ -188,7 +199,6 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
         __syncthreads();
     }
 
-    typedef in_traits<IN_KIND> IN;
     const uint32_t lane = threadIdx.x & (WAVE - 1);
     const uint32_t GW = gridDim.x * (FF_THREADS / WAVE);
     const uint32_t vblock = a.mix_xcds ? ((blockIdx.x & ~6u) | ((blockIdx.x & 2u) << 1) | ((blockIdx.x & 4u) >> 1)) : blockIdx.x; /* h2y_firf_vblock() */
@@ -232,12 +242,15 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
         ff_hist hb[2], hr[2]; /* rows 2s-11 .. 2s-1 of the 4:2:2 intermediate: Cb and Cr, this lane's columns 4L and 4L+2 */
         hb[0].fill(0u); hb[1].fill(0u); hr[0].fill(0u); hr[1].fill(0u);
 
-        ff_rows v; /* the row pair in hand; refilled row by row with the next one */
+        constexpr bool RAW = TIER == FF_TIER_LUT16;
+        constexpr int NREG = RAW ? 2 : 4;
+        uint32_t hmn[3] = {0x7C007C00u, 0x7C007C00u, 0x7C007C00u}, hmx[3] = {0u, 0u, 0u}; /* RAW: packed-half statistics, as k_fused_lut16's */
+        ff_rows<RAW> v; /* the row pair in hand; refilled row by row with the next one */
         uint32_t q0 = 2u * (s_begin < H2 - 1u ? s_begin : H2 - 1u) * WQ + qx; /* (scalar min: the loop's bounds stay in scalar registers) */
-        IN::load4q(io.in[0], q0, v.g0); IN::load4q(io.in[1], q0, v.b0); IN::load4q(io.in[2], q0, v.r0);
-        IN::load4q(io.in[0], q0 + WQ, v.g1); IN::load4q(io.in[1], q0 + WQ, v.b1); IN::load4q(io.in[2], q0 + WQ, v.r1);
+        ff_load<IN_KIND>(io.in[0], q0, v.g0); ff_load<IN_KIND>(io.in[1], q0, v.b0); ff_load<IN_KIND>(io.in[2], q0, v.r0);
+        ff_load<IN_KIND>(io.in[0], q0 + WQ, v.g1); ff_load<IN_KIND>(io.in[1], q0 + WQ, v.b1); ff_load<IN_KIND>(io.in[2], q0 + WQ, v.r1);
 #pragma unroll
-        for (int j = 0; j < 4; j++) asm volatile("" ::"v"(v.g0[j]), "v"(v.b0[j]), "v"(v.r0[j]), "v"(v.g1[j]), "v"(v.b1[j]), "v"(v.r1[j]));
+        for (int j = 0; j < NREG; j++) asm volatile("" ::"v"(v.g0[j]), "v"(v.b0[j]), "v"(v.r0[j]), "v"(v.g1[j]), "v"(v.b1[j]), "v"(v.r1[j]));
 
         for (uint32_t s = s_begin; s <= s_end; s++) {
             /* The block's sixteen waves are the sixteen strips of one band of rows: kept in step, they read a row of the
@@ -249,9 +262,17 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
             uint32_t yp[2][2], n_cb[2][2], n_cr[2][2]; /* new 4:2:2 values: [row][column 4L / 4L+2] */
 #pragma unroll
             for (int row = 0; row < 2; row++) {
-                const float(&gv)[4] = row ? v.g1 : v.g0;
-                const float(&bv)[4] = row ? v.b1 : v.b0;
-                const float(&rv)[4] = row ? v.r1 : v.r0;
+                const auto &gv = row ? v.g1 : v.g0; /* float[4], or (RAW) two registers of two halves */
+                const auto &bv = row ? v.b1 : v.b0;
+                const auto &rv = row ? v.r1 : v.r0;
+                uint32_t Y[4], Cb[4], Cr[4];
+                bool zrow = false;
+                if constexpr (RAW) { /* (always floor 0 / ceiling 1 here) every sample's maximum, a subsample of the minimum */
+                    if (row == 0) { hmn[0] = ff_pk_min_h(hmn[0], gv[0]); hmn[1] = ff_pk_min_h(hmn[1], bv[0]); hmn[2] = ff_pk_min_h(hmn[2], rv[0]); }
+                    hmx[0] = ff_pk_max_h(ff_pk_max_h(hmx[0], gv[0]), gv[1]);
+                    hmx[1] = ff_pk_max_h(ff_pk_max_h(hmx[1], bv[0]), bv[1]);
+                    hmx[2] = ff_pk_max_h(ff_pk_max_h(hmx[2], rv[0]), rv[1]);
+                } else {
                 if (PIPE == H2Y_PIPE_PQ_IDENT) { /* as k_fused_t1: every sample's maximum, a subsample of the minimum */
                     if (row == 0) { mm.add2(0, gv[0], gv[1]); mm.add2(1, bv[0], bv[1]); mm.add2(2, rv[0], rv[1]); }
                     else { mm.add2_max(0, gv[0], gv[1]); mm.add2_max(1, bv[0], bv[1]); mm.add2_max(2, rv[0], rv[1]); }
@@ -261,13 +282,12 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
                     mm.add2(1, bv[0], bv[1]); mm.add2(1, bv[2], bv[3]);
                     mm.add2(2, rv[0], rv[1]); mm.add2(2, rv[2], rv[3]);
                 }
-                uint32_t Y[4], Cb[4], Cr[4];
                 /* a row of zeros in every lane (letterbox bars)?  One compare per row for ordinary pictures: lane 0's first sample */
-                bool zrow = false;
                 if (TIER == FF_TIER_T1 && __builtin_expect(__builtin_amdgcn_ballot_w64(f2bits(gv[0]) != 0u) == 0, 0)) {
                     const uint32_t z = (f2bits(gv[1]) | f2bits(gv[2]) | f2bits(gv[3])) | (f2bits(bv[0]) | f2bits(bv[1]) | f2bits(bv[2])) |
                                        (f2bits(bv[3]) | f2bits(rv[0]) | f2bits(rv[1])) | (f2bits(rv[2]) | f2bits(rv[3]));
                     zrow = __builtin_amdgcn_ballot_w64(z != 0u) == 0;
+                }
                 }
                 if (zrow) {
                     const uint32_t y0 = s_black[0], cb0 = s_black[1], cr0 = s_black[2];
@@ -276,12 +296,13 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
                 } else
 #pragma unroll
                 for (int col = 0; col < 4; col++) {
-#ifdef H2Y_EXP_NOCOMPUTE /* timing experiment only (wrong bytes): the step's loads, FIR stages and stores without the pixel arithmetic */
-                    Y[col] = f2bits(gv[col]) >> 21; Cb[col] = f2bits(bv[col]) >> 21; Cr[col] = f2bits(rv[col]) >> 21;
-                    continue;
+                    if constexpr (RAW) {
+                        const uint32_t hg = (gv[col >> 1] >> (16 * (col & 1))) & 0xFFFFu, hb = (bv[col >> 1] >> (16 * (col & 1))) & 0xFFFFu,
+                                       hr = (rv[col >> 1] >> (16 * (col & 1))) & 0xFFFFu;
+#ifdef H2Y_EXP_NOCOMPUTE /* timing experiment only (wrong bytes) */
+                        Y[col] = hg >> 5; Cb[col] = hb >> 5; Cr[col] = hr >> 5;
+                        continue;
 #endif
-                    if (TIER == FF_TIER_LUT16) {
-                        const uint32_t hg = half_bits_of(gv[col]), hb = half_bits_of(bv[col]), hr = half_bits_of(rv[col]);
                         const float lg = s_lut[hg & (H2Y_LUT16_N - 1)], lb = s_lut[hb & (H2Y_LUT16_N - 1)], lr = s_lut[hr & (H2Y_LUT16_N - 1)];
                         __builtin_amdgcn_sched_barrier(0);
                         const float g = pix_scale(lg, pp.mulY, pp.addY), b = pix_scale(lb, pp.mulC, pp.addC), rr = pix_scale(lr, pp.mulC, pp.addC);
@@ -290,15 +311,19 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
                         const bool fl = (((hg | hb | hr) & ~(uint32_t)(H2Y_LUT16_N - 1)) != 0) | um; /* negative, >= 2.0, inf, NaN; or the division guard */
                         const uint64_t fm = __builtin_amdgcn_ballot_w64(fl);
                         if (__builtin_expect(fm != 0, 0)) {
+                            const float fg = ff_half_to_float(hg), fb = ff_half_to_float(hb), fr = ff_half_to_float(hr);
                             if (fl) {
-                                const ycc k = pixel_careful<MODE>(&s_pp, gv[col], bv[col], rv[col]);
+                                const ycc k = pixel_careful<MODE>(&s_pp, fg, fb, fr);
                                 Y[col] = k.y; Cb[col] = k.cb; Cr[col] = k.cr;
                             }
                             flagged += (uint32_t)__popcll(fm);
-                            low_m |= __builtin_amdgcn_ballot_w64(fl && min3f(gv[col], bv[col], rv[col]) <= -1.0f);
+                            low_m |= __builtin_amdgcn_ballot_w64(fl && min3f(fg, fb, fr) <= -1.0f);
                         }
-                        continue;
-                    }
+                    } else {
+#ifdef H2Y_EXP_NOCOMPUTE /* timing experiment only (wrong bytes): the step's loads, FIR stages and stores without the pixel arithmetic */
+                    Y[col] = f2bits(gv[col]) >> 21; Cb[col] = f2bits(bv[col]) >> 21; Cr[col] = f2bits(rv[col]) >> 21;
+                    continue;
+#endif
                     const float Gn = norm1<PIPE>(pp, 0, gv[col]), Bn = norm1<PIPE>(pp, 1, bv[col]), Rn = norm1<PIPE>(pp, 2, rv[col]);
                     const pq_rec1 cg = pq_t1_fetch(Gn, s_t1), cb = pq_t1_fetch(Bn, s_t1), cr = pq_t1_fetch(Rn, s_t1);
                     __builtin_amdgcn_sched_barrier(0);
@@ -325,6 +350,7 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
                         flagged += (uint32_t)__popcll(fm);
                         if (PIPE == H2Y_PIPE_PQ_IDENT) low_m |= __builtin_amdgcn_ballot_w64(fl && min3f(Gn, Bn, Rn) <= -1.0f);
                     }
+                    }
                 }
                 yp[row][0] = pix_yuv_clamp<true>(pp, Y[0], false) | (pix_yuv_clamp<true>(pp, Y[1], false) << 16);
                 yp[row][1] = pix_yuv_clamp<true>(pp, Y[2], false) | (pix_yuv_clamp<true>(pp, Y[3], false) << 16);
@@ -335,17 +361,17 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
                 ff_hstage(Cr, e, maxcv, n_cr[row][0], n_cr[row][1]);
 #endif
                 if (row == 0) { /* row 0 of the next step, into the registers just read for the last time */
-                    IN::load4q(io.in[0], q0n, v.g0);
-                    IN::load4q(io.in[1], q0n, v.b0);
-                    IN::load4q(io.in[2], q0n, v.r0);
+                    ff_load<IN_KIND>(io.in[0], q0n, v.g0);
+                    ff_load<IN_KIND>(io.in[1], q0n, v.b0);
+                    ff_load<IN_KIND>(io.in[2], q0n, v.r0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
             gstore_nt<u32x2>(io.out, q0, u32x2{yp[0][0], yp[0][1]});
             gstore_nt<u32x2>(io.out, q0 + WQ, u32x2{yp[1][0], yp[1][1]});
-            IN::load4q(io.in[0], q0n + WQ, v.g1);
-            IN::load4q(io.in[1], q0n + WQ, v.b1);
-            IN::load4q(io.in[2], q0n + WQ, v.r1);
+            ff_load<IN_KIND>(io.in[0], q0n + WQ, v.g1);
+            ff_load<IN_KIND>(io.in[1], q0n + WQ, v.b1);
+            ff_load<IN_KIND>(io.in[2], q0n + WQ, v.r1);
 
             if (s >= H2) { /* below the picture: both new rows are its last row (convert.cpp:337-347) */
 #pragma unroll
@@ -390,7 +416,16 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
         }
         /* drain the loads the last step asked for (their registers are reused by the next unit's first loads) */
 #pragma unroll
-        for (int j = 0; j < 4; j++) asm volatile("" ::"v"(v.g0[j]), "v"(v.b0[j]), "v"(v.r0[j]), "v"(v.g1[j]), "v"(v.b1[j]), "v"(v.r1[j]));
+        for (int j = 0; j < NREG; j++) asm volatile("" ::"v"(v.g0[j]), "v"(v.b0[j]), "v"(v.r0[j]), "v"(v.g1[j]), "v"(v.b1[j]), "v"(v.r1[j]));
+        if constexpr (RAW) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) { /* fold the two packed halves, widen; pic_stats' initial values when nothing beat them (k_fused_lut16) */
+                mm.lo[c] = fminf(ff_half_to_float(hmn[c] & 0xFFFFu), ff_half_to_float(hmn[c] >> 16));
+                mm.hi[c] = fmaxf(ff_half_to_float(hmx[c] & 0xFFFFu), ff_half_to_float(hmx[c] >> 16));
+                mm.lo[c] = mm.lo[c] > 65504.0f ? 3.402823466e+38f : mm.lo[c];
+                mm.hi[c] = mm.hi[c] <= 0.0f ? 1.175494351e-38f : mm.hi[c];
+            }
+        }
         const size_t slot = (size_t)f * a.units_per_frame + r;
         wave_store_mm(mm, a.partial + slot * 6);
         if (lane == 0) {

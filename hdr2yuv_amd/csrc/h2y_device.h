@@ -388,4 +388,18 @@ template <int THREADS> __device__ __forceinline__ void stage_table(const void *t
     stage16<THREADS, 2 * H2Y_PQ_NREC>(table, s_tab);
 }
 
+/* The half-input kernels' table in LDS: PQ10000_r of every half in [0, 2) (a.lut16) taken through the scale step as well --
+ * convert.cpp:1123-1145, one binary32 multiply and one add, the same for every pixel of a launch -- once with the luma
+ * constants (the G / Y plane), once with the chroma ones (B and R): 2 x 64 KB instead of 64 KB and six instructions a pixel. */
+template <int THREADS> __device__ __forceinline__ void stage_lut16_scaled(const float *lut, const pix_params &pp, float *s_y, float *s_c)
+{
+    const f32x4 *g = reinterpret_cast<const f32x4 *>(lut);
+    f32x4 *ly = reinterpret_cast<f32x4 *>(s_y), *lc = reinterpret_cast<f32x4 *>(s_c);
+    for (int i = threadIdx.x; i < H2Y_LUT16_N / 4; i += THREADS) {
+        const f32x4 q = g[i];
+        ly[i] = f32x4{pix_scale(q.x, pp.mulY, pp.addY), pix_scale(q.y, pp.mulY, pp.addY), pix_scale(q.z, pp.mulY, pp.addY), pix_scale(q.w, pp.mulY, pp.addY)};
+        lc[i] = f32x4{pix_scale(q.x, pp.mulC, pp.addC), pix_scale(q.y, pp.mulC, pp.addC), pix_scale(q.z, pp.mulC, pp.addC), pix_scale(q.w, pp.mulC, pp.addC)};
+    }
+}
+
 #endif /* H2Y_DEVICE_H */

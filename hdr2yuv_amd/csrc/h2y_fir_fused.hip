@@ -170,15 +170,15 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
     if (a.block_clock && threadIdx.x == 0) a.block_clock[2 * blockIdx.x] = wall_clock64();
     __shared__ pq_rec1 s_t1[TIER == FF_TIER_T1 ? H2Y_T1_NREC : 1];
     __shared__ pq_recA s_t2[TIER == FF_TIER_T1 ? 2 * H2Y_PQ_NREC : 1]; /* A records, then B records */
-    __shared__ float s_lut[TIER == FF_TIER_LUT16 ? H2Y_LUT16_N : 1];
+    __shared__ float s_lut_y[TIER == FF_TIER_LUT16 ? H2Y_LUT16_N : 1], s_lut_c[TIER == FF_TIER_LUT16 ? H2Y_LUT16_N : 1]; /* stage_lut16_scaled() */
     __shared__ pix_params s_pp;
     const pq_recA *sA = s_t2;
     const pq_recB *sB = reinterpret_cast<const pq_recB *>(s_t2 + (TIER == FF_TIER_T1 ? H2Y_PQ_NREC : 0));
+    const pix_params pp = with_assumed(a.pp, a.assumed);
     if (TIER == FF_TIER_T1) {
         stage16<FF_THREADS, H2Y_T1_NREC>(a.table1, s_t1);
         stage_table<FF_THREADS>(a.table, s_t2);
-    } else stage16<FF_THREADS, H2Y_LUT16_N / 4>(a.lut16, s_lut);
-    const pix_params pp = with_assumed(a.pp, a.assumed);
+    } else stage_lut16_scaled<FF_THREADS>(a.lut16, pp, s_lut_y, s_lut_c);
     t1_sens sn = a.sn;
     asm volatile("" : "+v"(sn.a_lo), "+v"(sn.a_hi));
     if (threadIdx.x == 0) s_pp = pp;
@@ -303,9 +303,8 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
                         Y[col] = hg >> 5; Cb[col] = hb >> 5; Cr[col] = hr >> 5;
                         continue;
 #endif
-                        const float lg = s_lut[hg & (H2Y_LUT16_N - 1)], lb = s_lut[hb & (H2Y_LUT16_N - 1)], lr = s_lut[hr & (H2Y_LUT16_N - 1)];
+                        const float g = s_lut_y[hg & (H2Y_LUT16_N - 1)], b = s_lut_c[hb & (H2Y_LUT16_N - 1)], rr = s_lut_c[hr & (H2Y_LUT16_N - 1)];
                         __builtin_amdgcn_sched_barrier(0);
-                        const float g = pix_scale(lg, pp.mulY, pp.addY), b = pix_scale(lb, pp.mulC, pp.addC), rr = pix_scale(lr, pp.mulC, pp.addC);
                         bool um;
                         pix_matrix<MODE, false>(pp, g, b, rr, Y[col], Cb[col], Cr[col], &um);
                         const bool fl = (((hg | hb | hr) & ~(uint32_t)(H2Y_LUT16_N - 1)) != 0) | um; /* negative, >= 2.0, inf, NaN; or the division guard */

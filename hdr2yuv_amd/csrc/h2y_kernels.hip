@@ -1015,14 +1015,14 @@ __global__ __launch_bounds__(H2Y_LOOP_THREADS) void k_fused_lut16(fused_args a)
 {
     typedef typename lut16_raw<COLS>::type RV;
     constexpr int NH = COLS / 4; /* 4-column halves per tile */
-    __shared__ float s_lut[H2Y_LUT16_N];
+    __shared__ float s_lut_y[H2Y_LUT16_N], s_lut_c[H2Y_LUT16_N]; /* PQ and the scale step of every half in [0, 2): luma / chroma constants */
     __shared__ pix_params s_pp;
     __shared__ uint32_t s_claim[H2Y_CLAIM_FRAMES], s_scratch[WAVE];
+    const pix_params pp = with_assumed(a.pp, a.assumed);
     {
-        stage16<H2Y_LOOP_THREADS, H2Y_LUT16_N / 4>(a.lut16, s_lut);
+        stage_lut16_scaled<H2Y_LOOP_THREADS>(a.lut16, pp, s_lut_y, s_lut_c);
         if (threadIdx.x < H2Y_CLAIM_FRAMES) s_claim[threadIdx.x] = 0u;
     }
-    const pix_params pp = with_assumed(a.pp, a.assumed);
     if (threadIdx.x == 0) s_pp = pp;
     __syncthreads();
 
@@ -1102,13 +1102,10 @@ __global__ __launch_bounds__(H2Y_LOOP_THREADS) void k_fused_lut16(fused_args a)
                         const uint32_t wr = raw[2][row][2 * hf + (col >> 1)];
                         const uint32_t hg = col & 1 ? wg >> 16 : wg & 0xFFFFu, hb = col & 1 ? wb >> 16 : wb & 0xFFFFu, hr = col & 1 ? wr >> 16 : wr & 0xFFFFu;
                         /* the three table reads of a pixel on their way before the first is used (as in k_fused_t1) */
-                        const float lg = s_lut[hg & (H2Y_LUT16_N - 1)], lb = s_lut[hb & (H2Y_LUT16_N - 1)], lr = s_lut[hr & (H2Y_LUT16_N - 1)];
+                        const float g = s_lut_y[hg & (H2Y_LUT16_N - 1)], b = s_lut_c[hb & (H2Y_LUT16_N - 1)], r = s_lut_c[hr & (H2Y_LUT16_N - 1)];
 #ifndef H2Y_LUT_NOBARRIER
                         __builtin_amdgcn_sched_barrier(0);
 #endif
-                        const float g = pix_scale(lg, pp.mulY, pp.addY);
-                        const float b = pix_scale(lb, pp.mulC, pp.addC);
-                        const float r = pix_scale(lr, pp.mulC, pp.addC);
                         bool um;
                         pix_matrix<MODE, false>(pp, g, b, r, Y[col], Cb[col], Cr[col], &um);
                         const bool outside = ((hg | hb | hr) & ~(uint32_t)(H2Y_LUT16_N - 1)) != 0; /* negative, >= 2.0, inf, NaN */

@@ -1095,6 +1095,11 @@ __global__ __launch_bounds__(H2Y_LOOP_THREADS) void k_fused_lut16(fused_args a)
 #pragma unroll
                 for (int hf = 0; hf < NH; hf++) {
                     uint32_t Y[4], Cb[4], Cr[4];
+                    /* a sample outside the table (sign or bit 14 set: negative, >= 2.0, inf, NaN) among this lane's four
+                     * columns of the row?  Looked for once on the packed halves, not per pixel: the four pixels then all
+                     * take the careful tier */
+                    const bool outside = (((raw[0][row][2 * hf] | raw[0][row][2 * hf + 1] | raw[1][row][2 * hf]) |
+                                           (raw[1][row][2 * hf + 1] | raw[2][row][2 * hf] | raw[2][row][2 * hf + 1])) & 0xC000C000u) != 0u;
 #pragma unroll
                     for (int col = 0; col < 4; col++) {
                         const uint32_t wg = raw[0][row][2 * hf + (col >> 1)];
@@ -1108,7 +1113,6 @@ __global__ __launch_bounds__(H2Y_LOOP_THREADS) void k_fused_lut16(fused_args a)
 #endif
                         bool um;
                         pix_matrix<MODE, false>(pp, g, b, r, Y[col], Cb[col], Cr[col], &um);
-                        const bool outside = ((hg | hb | hr) & ~(uint32_t)(H2Y_LUT16_N - 1)) != 0; /* negative, >= 2.0, inf, NaN */
                         if (__builtin_expect(outside | um, 0)) {
                             const ycc c = pixel_careful<MODE>(&s_pp, half_bits_to_float(hg), half_bits_to_float(hb), half_bits_to_float(hr));
                             Y[col] = c.y; Cb[col] = c.cb; Cr[col] = c.cr;

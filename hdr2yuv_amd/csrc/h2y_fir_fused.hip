@@ -266,7 +266,8 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
                 const auto &bv = row ? v.b1 : v.b0;
                 const auto &rv = row ? v.r1 : v.r0;
                 uint32_t Y[4], Cb[4], Cr[4];
-                bool zrow = false, row_out = false;
+                bool zrow = false;
+                uint64_t row_out_m = 0; /* RAW: lanes with an out-of-table sample in this row (a compare's own lane mask) */
                 if constexpr (RAW) { /* (always floor 0 / ceiling 1 here) every sample's maximum, a subsample of the minimum */
                     if (row == 0) { hmn[0] = ff_pk_min_h(hmn[0], gv[0]); hmn[1] = ff_pk_min_h(hmn[1], bv[0]); hmn[2] = ff_pk_min_h(hmn[2], rv[0]); }
                     hmx[0] = ff_pk_max_h(ff_pk_max_h(hmx[0], gv[0]), gv[1]);
@@ -274,7 +275,7 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
                     hmx[2] = ff_pk_max_h(ff_pk_max_h(hmx[2], rv[0]), rv[1]);
                     /* a sample outside the table (sign or bit 14 set: negative, >= 2.0, inf, NaN) in this lane's row?  Looked for
                      * once per row on the packed halves, not per pixel: such a lane's four pixels all take the careful tier */
-                    row_out = (((gv[0] | gv[1] | bv[0]) | (bv[1] | rv[0] | rv[1])) & 0xC000C000u) != 0u;
+                    row_out_m = __builtin_amdgcn_ballot_w64((((gv[0] | gv[1] | bv[0]) | (bv[1] | rv[0] | rv[1])) & 0xC000C000u) != 0u);
                 } else {
                 if (PIPE == H2Y_PIPE_PQ_IDENT) { /* as k_fused_t1: every sample's maximum, a subsample of the minimum */
                     if (row == 0) { mm.add2(0, gv[0], gv[1]); mm.add2(1, bv[0], bv[1]); mm.add2(2, rv[0], rv[1]); }
@@ -310,9 +311,10 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
                         __builtin_amdgcn_sched_barrier(0);
                         bool um;
                         pix_matrix<MODE, false>(pp, g, b, rr, Y[col], Cb[col], Cr[col], &um);
-                        const bool fl = row_out | um; /* a sample of the row outside the table, or the division guard */
-                        const uint64_t fm = __builtin_amdgcn_ballot_w64(fl);
+                        /* a sample of the row outside the table, or the division guard (lane masks ORed in scalar registers) */
+                        const uint64_t fm = __builtin_amdgcn_ballot_w64(um) | row_out_m;
                         if (__builtin_expect(fm != 0, 0)) {
+                            const bool fl = ((fm >> lane) & 1u) != 0;
                             const float fg = ff_half_to_float(hg), fb = ff_half_to_float(hb), fr = ff_half_to_float(hr);
                             if (fl) {
                                 const ycc k = pixel_careful<MODE>(&s_pp, fg, fb, fr);

@@ -28,7 +28,7 @@ EXPORTS = [
     "h2y_abi_version", "h2y_frame_bytes", "h2y_plane_bytes", "h2y_desc_check", "h2y_ctx_create", "h2y_ctx_destroy",
     "h2y_last_error", "h2y_ctx_set_stream", "h2y_convert_frame", "h2y_convert_batch", "h2y_convert_batch_enqueue",
     "h2y_batch_finish", "h2y_pic_stats", "h2y_matrix_convert", "h2y_subsample_420", "h2y_last_kernel_ms", "h2y_last_kernel_name", "h2y_last_kernel_variant",
-    "h2y_matrix_inverse", "h2y_upsample_444", "h2y_inverse_420", "h2y_ctx_set_option", "h2y_stream_open", "h2y_stream_input", "h2y_stream_submit", "h2y_stream_output", "h2y_stream_close",
+    "h2y_matrix_inverse", "h2y_upsample_444", "h2y_inverse_420", "h2y_inverse_frame", "h2y_ctx_set_option", "h2y_stream_open", "h2y_stream_input", "h2y_stream_submit", "h2y_stream_output", "h2y_stream_close",
 ]
 
 
@@ -154,6 +154,8 @@ def load_library():
     L.h2y_upsample_444.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint, C.c_uint, C.c_void_p, C.c_void_p]
     L.h2y_inverse_420.restype = C.c_int
     L.h2y_inverse_420.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    L.h2y_inverse_frame.restype = C.c_int
+    L.h2y_inverse_frame.argtypes = [C.c_void_p] + [C.c_int] * 8 + [C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.h2y_stream_open.restype = C.c_int
     L.h2y_stream_open.argtypes = [C.c_void_p, C.POINTER(H2YDesc), C.c_int]
     L.h2y_stream_input.restype = C.c_int
@@ -305,6 +307,17 @@ class Context:
         ip = (C.c_void_p * 3)(*[self._ptr(p) for p in in_planes])
         op = (C.c_void_p * 3)(*[self._ptr(p) for p in out_planes])
         self._check(self.lib.h2y_inverse_420(self.h, width, height, in_depth, in_full_range, in_matrix, out_depth, algorithm, ip, op))
+
+    def inverse_frame(self, width, height, in_chroma, in_depth, in_full_range, in_matrix, out_depth, algorithm, in_planes):
+        """Host U16 planes (Y, Cb/Dz, Cr/Dx; 4:4:4 or 4:2:0) -> host U16 planes (G, B, R): the .yuv -> .tiff flow on one frame."""
+        import numpy as np
+
+        ins = [np.ascontiguousarray(p, dtype=np.uint16) for p in in_planes]
+        outs = [np.empty(width * height, np.uint16) for _ in range(3)]
+        ip = (C.c_void_p * 3)(*[p.ctypes.data for p in ins])
+        op = (C.c_void_p * 3)(*[p.ctypes.data for p in outs])
+        self._check(self.lib.h2y_inverse_frame(self.h, width, height, in_chroma, in_depth, in_full_range, in_matrix, out_depth, algorithm, ip, op))
+        return outs
 
     # ---- host <-> device pipeline -----------------------------------------------------------
     def stream_open(self, d, depth=3) -> None:

@@ -1,61 +1,36 @@
 /*
- * hdr2yuv (MI355X build) -- host program with the reference's command-line
- * surface (hdr2yuv.cpp:73-263) for the in-memory convert path.  It reads raw
- * planar input, hands the planes to the C-ABI (include/hdr2yuv_hip.h) and
- * appends the .yuv frame exactly as write_yuv() does (tiff.cpp:440: the file is
- * opened in append mode; planes Y, Cb, Cr, little-endian 16-bit).
+ * hdr2yuv (MI355X build) -- host program with the reference's command-line surface (hdr2yuv.cpp:73-263) and its
+ * resolution of unset attributes (h2y_cli_args.h) for the in-memory convert path.  It reads raw planar input, hands the
+ * planes to the C-ABI (include/hdr2yuv_hip.h) and writes the .yuv frames where write_yuv() would append them
+ * (tiff.cpp:440: the file is opened in append mode; planes Y, Cb, Cr, little-endian 16-bit).
  *
- * File decoding stays where the reference has it (exr.cpp / tiff.cpp / dpx.cpp
- * need OpenEXR and libtiff): this binary takes the formats that need no codec:
- *   .yuv / .rgb  16-bit planar integer (hdr2yuv.cpp:582-656; .rgb is R,G,B in
- *                the file, planes 2,0,1 in memory)
- *   .f32 / .f16  raw planar float / half in G,B,R plane order -- what read_exr()
- *                (exr.cpp:233-235) or dpx_read() leave in memory
- *   --synthetic N  the seeded test frame of SURVEY 8c (no input file)
- * Unknown flags warn and are skipped, as in the reference (hdr2yuv.cpp:258).
- * Numeric codes only for the enum flags (the reference's name lookup indexes
- * its table with the wrong variable).
+ * File decoding stays where the reference has it (exr.cpp / tiff.cpp / dpx.cpp need OpenEXR and libtiff): this binary
+ * takes the formats that need no codec:
+ *   .yuv / .rgb  16-bit planar integer (hdr2yuv.cpp:582-656; .rgb is R,G,B in the file, planes 2,0,1 in memory)
+ *   .f32 / .f16  raw planar float / half in G,B,R plane order -- what dpx_read() or read_exr() (exr.cpp:233-235) leave in
+ *                memory; the attributes those readers force on the input picture are forced here too
+ *   --synthetic N  the seeded test frame of SURVEY 8c (no input file), treated as an .exr-like float input
+ * and, from .yuv input, .rgb output: the .yuv -> .tiff flow (hdr2yuv.cpp:818-819, matrix_inverse) with the samples
+ * write_tiff() would interleave written as planes R, G, B instead (no libtiff here).
+ *
+ * Several GPUs (--gpus N, an addition: the reference converts one frame per process): one host thread per GPU, each with
+ * its own context and pinned ring; thread r takes a contiguous block of the frame indices (the split of
+ * hdr2yuv_amd/shard.py), reads frame k at its offset in the source (hdr2yuv.cpp:624) and writes it at
+ * `size of the file at start + k x frame bytes` -- the bytes N appending runs in frame order would have left (tiff.cpp:440).
  */
+#include <cerrno>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fcntl.h>
 #include <string>
+#include <sys/stat.h>
+#include <thread>
+#include <unistd.h>
 #include <vector>
 
-#include "../../include/hdr2yuv_hip.h"
-
-struct args {
-    const char *src = nullptr, *dst = nullptr;
-    int src_w = 0, src_h = 0, dst_w = 0, dst_h = 0;
-    int src_depth = 0, dst_depth = 0;
-    int src_half = 0;
-    int src_chroma = -1, dst_chroma = -1;
-    int start_frame = 0, n_frames = 1, verbose = 0;
-    int src_prim = -1, dst_prim = -1, src_mat = -1, dst_mat = -1, src_tr = -1, dst_tr = -1;
-    int src_full = -1, dst_full = -1;
-    int resampler = 1; /* the reference leaves this uninitialised; FIR as in make.sh's example */
-    int synthetic = -1;
-    int device = 0;
-};
-
-static void help()
-{
-    printf("hdr2yuv (gfx950): --src_filename F --dst_filename F.yuv --src_pic_width W --src_pic_height H\n"
-           "  [--src_bit_depth N] [--dst_bit_depth N] [--src_half_float_flag 0|1] [--src_chroma_format_idc 3]\n"
-           "  [--dst_chroma_format_idc 1|3] [--src_start_frame K] [--n_frames N] [--verbose_level L]\n"
-           "  [--src_colour_primaries P] [--dst_colour_primaries P] [--src_matrix_coeffs M] [--dst_matrix_coeffs M]\n"
-           "  [--src_transfer_characteristics T] [--dst_transfer_characteristics T]\n"
-           "  [--src_video_full_range_flag 0|1] [--dst_video_full_range_flag 0|1] [--chroma_resampler_type 0|1]\n"
-           "  extra: [--synthetic SEEDFRAME] [--device D]\n"
-           "input by extension: .yuv .rgb (16-bit planar), .f32 .f16 (raw planar float, plane order G,B,R)\n");
-}
-
-static const char *ext_of(const char *fn)
-{
-    const char *dot = fn ? strrchr(fn, '.') : nullptr;
-    return dot ? dot + 1 : "";
-}
+#include "h2y_cli_args.h"
 
 static uint16_t f32_to_f16(float f)
 {
@@ -78,168 +53,221 @@ static uint16_t f32_to_f16(float f)
     return (uint16_t)(sign | r);
 }
 
+/* the seeded frame of SURVEY 8c: frame k of a run uses seed 12345 + k */
+static void synth_fill(const h2y_desc &d, void *const planes[3], uint32_t seed)
+{
+    const size_t n = (size_t)d.width * d.height;
+    uint32_t s = seed;
+    for (int c = 0; c < 3; c++) {
+        for (size_t i = 0; i < n; i++) {
+            s = s * 1664525u + 1013904223u;
+            float v = (float)(s >> 8) * (1.0f / 16777216.0f);
+            if (i == 0) v = 0.0f;
+            if (i == 1) v = 1.0f;
+            if (d.in_sample_type == H2Y_SAMPLE_F16) ((uint16_t *)planes[c])[i] = f32_to_f16(v);
+            else ((float *)planes[c])[i] = v;
+        }
+    }
+}
+
+static bool write_at(int fd, const void *buf, size_t n, off_t at)
+{
+    const char *p = (const char *)buf;
+    while (n) {
+        ssize_t w = pwrite(fd, p, n, at);
+        if (w < 0) {
+            if (errno == EINTR) continue;
+            return false;
+        }
+        p += w;
+        at += w;
+        n -= (size_t)w;
+    }
+    return true;
+}
+
+struct block { /* one thread's share: frames [first, first + count) of the run, on `device` */
+    int device = 0;
+    long first = 0, count = 0;
+    std::string err;
+    long done = 0;
+};
+
+/* forward path: frames [first, first+count) through one context's pinned ring */
+static void run_block(const cli_args &a, const h2y_desc &d, int fd_out, off_t base, block *b)
+{
+    h2y_ctx *ctx = nullptr;
+    FILE *fin = nullptr;
+    auto fail = [&](const std::string &m) {
+        b->err = m;
+        if (ctx) { h2y_stream_close(ctx); h2y_ctx_destroy(ctx); }
+        if (fin) fclose(fin);
+    };
+    if (b->count < 1) return;
+    if (h2y_ctx_create(b->device, &ctx)) return fail(h2y_last_error(nullptr));
+    const size_t pb = h2y_plane_bytes(&d), ob = h2y_frame_bytes(&d);
+    if (a.in_type != CLI_IN_SYNTH) {
+        fin = fopen(a.src, "rb");
+        if (!fin) return fail(std::string("unable to open file ") + a.src);
+        if (fseeko(fin, (off_t)(3 * pb) * (off_t)(a.start_frame + b->first), SEEK_SET)) return fail("seek failed"); /* hdr2yuv.cpp:624 */
+    }
+    /* The reader fills the pinned slot of the pipeline directly, the writer drains what comes out of it two frames
+     * later: upload, conversion and download of neighbouring frames overlap. */
+    const int depth = 3;
+    if (h2y_stream_open(ctx, &d, depth)) return fail(h2y_last_error(ctx));
+    long in_flight = 0;
+    auto drain_one = [&]() -> bool {
+        const uint16_t *yuv = nullptr;
+        if (h2y_stream_output(ctx, &yuv)) { fail(h2y_last_error(ctx)); return false; }
+        const long k = b->first + b->done;
+        if (!write_at(fd_out, yuv, ob, base + (off_t)k * (off_t)ob)) { fail(std::string("short write to ") + a.dst); return false; }
+        if (a.verbose > 0) printf("frame %ld: %zu bytes written to %s (device %d)\n", k, ob, a.dst, b->device);
+        b->done++;
+        in_flight--;
+        return true;
+    };
+    for (long f = 0; f < b->count; f++) {
+        void *planes[3];
+        if (h2y_stream_input(ctx, planes)) return fail(h2y_last_error(ctx));
+        if (fin) {
+            /* file plane order -> memory planes (0=G/Y, 1=B/Cb, 2=R/Cr); .rgb holds R,G,B (hdr2yuv.cpp:635-637) */
+            const int order_rgb[3] = {2, 0, 1}, order_nat[3] = {0, 1, 2};
+            const int *ord = a.in_type == CLI_IN_RGB ? order_rgb : order_nat;
+            size_t got = 0;
+            for (int k = 0; k < 3; k++) got += fread(planes[ord[k]], 1, pb, fin);
+            if (got != 3 * pb) return fail("only " + std::to_string(got) + " bytes read from " + a.src + ", expecting " + std::to_string(3 * pb));
+        } else synth_fill(d, planes, 12345u + (uint32_t)(a.synthetic + a.start_frame + b->first + f));
+        if (h2y_stream_submit(ctx)) return fail(h2y_last_error(ctx));
+        in_flight++;
+        if (in_flight == depth - 1 && !drain_one()) return;
+    }
+    while (in_flight > 0)
+        if (!drain_one()) return;
+    h2y_stream_close(ctx);
+    if (fin) fclose(fin);
+    h2y_ctx_destroy(ctx);
+}
+
+/* .yuv -> RGB (matrix_inverse), frame by frame on the host-buffer entry */
+static void run_block_inverse(const cli_args &a, int fd_out, off_t base, block *b)
+{
+    h2y_ctx *ctx = nullptr;
+    FILE *fin = nullptr;
+    auto fail = [&](const std::string &m) {
+        b->err = m;
+        if (ctx) h2y_ctx_destroy(ctx);
+        if (fin) fclose(fin);
+    };
+    if (b->count < 1) return;
+    if (h2y_ctx_create(b->device, &ctx)) return fail(h2y_last_error(nullptr));
+    const size_t n = (size_t)a.in.width * a.in.height;
+    const bool sub = a.in.chroma_format_idc == H2Y_CHROMA_420;
+    const size_t nc = sub ? (size_t)(a.in.width / 2) * (a.in.height / 2) : n, in_frame = (n + 2 * nc) * 2, out_frame = 3 * n * 2;
+    std::vector<uint16_t> in(n + 2 * nc), out(3 * n);
+    fin = fopen(a.src, "rb");
+    if (!fin) return fail(std::string("unable to open file ") + a.src);
+    if (fseeko(fin, (off_t)in_frame * (off_t)(a.start_frame + b->first), SEEK_SET)) return fail("seek failed");
+    for (long f = 0; f < b->count; f++) {
+        if (fread(in.data(), 1, in_frame, fin) != in_frame) return fail(std::string("short read from ") + a.src);
+        const uint16_t *ip[3] = {in.data(), in.data() + n, in.data() + n + nc};
+        uint16_t *op[3] = {out.data() + n, out.data() + 2 * n, out.data()}; /* planes G,B,R -> file order R,G,B (write_tiff: R,G,B per pixel) */
+        if (h2y_inverse_frame(ctx, a.in.width, a.in.height, a.in.chroma_format_idc, a.in.bit_depth, a.in.video_full_range_flag,
+                              a.in.matrix_coeffs, a.out.bit_depth, a.resampler, ip, op))
+            return fail(h2y_last_error(ctx));
+        const long k = b->first + f;
+        if (!write_at(fd_out, out.data(), out_frame, base + (off_t)k * (off_t)out_frame)) return fail(std::string("short write to ") + a.dst);
+        b->done++;
+    }
+    fclose(fin);
+    h2y_ctx_destroy(ctx);
+}
+
 int main(int argc, char **argv)
 {
-    args a;
-    for (int i = 1; i < argc; i++) {
-        auto is = [&](const char *n) { return !strcmp(argv[i], n); };
-        auto val = [&]() -> const char * { return (i + 1 < argc) ? argv[++i] : "0"; };
-        if (is("--help")) { help(); return 0; }
-        else if (is("--src_filename")) a.src = val();
-        else if (is("--dst_filename")) a.dst = val();
-        else if (is("--ref_filename") || is("--sigma_compare") || is("--alpha_channel") || is("--cutout_hd") || is("--cutout_qhd") ||
-                 is("--dst_half_float_flag")) (void)val(); /* parsed by the reference, not on this path */
-        else if (is("--src_pic_width")) a.src_w = atoi(val());
-        else if (is("--src_pic_height")) a.src_h = atoi(val());
-        else if (is("--dst_pic_width")) a.dst_w = atoi(val());
-        else if (is("--dst_pic_height")) a.dst_h = atoi(val());
-        else if (is("--src_bit_depth")) a.src_depth = atoi(val());
-        else if (is("--dst_bit_depth")) a.dst_depth = atoi(val());
-        else if (is("--src_half_float_flag")) a.src_half = atoi(val());
-        else if (is("--src_chroma_format_idc")) a.src_chroma = atoi(val());
-        else if (is("--dst_chroma_format_idc")) a.dst_chroma = atoi(val());
-        else if (is("--src_start_frame")) a.start_frame = atoi(val());
-        else if (is("--n_frames")) a.n_frames = atoi(val());
-        else if (is("--verbose_level")) a.verbose = atoi(val());
-        else if (is("--src_colour_primaries")) a.src_prim = atoi(val());
-        else if (is("--dst_colour_primaries")) a.dst_prim = atoi(val());
-        else if (is("--src_matrix_coeffs")) a.src_mat = atoi(val());
-        else if (is("--dst_matrix_coeffs")) a.dst_mat = atoi(val());
-        else if (is("--src_transfer_characteristics")) a.src_tr = atoi(val());
-        else if (is("--dst_transfer_characteristics")) a.dst_tr = atoi(val());
-        else if (is("--src_video_full_range_flag")) a.src_full = atoi(val());
-        else if (is("--dst_video_full_range_flag")) a.dst_full = atoi(val());
-        else if (is("--chroma_resampler_type")) a.resampler = atoi(val());
-        else if (is("--synthetic")) a.synthetic = atoi(val());
-        else if (is("--device")) a.device = atoi(val());
-        else printf("WARNING: unrecognized argument: %s\n", argv[i]);
+    cli_args a;
+    cli_parse(a, argc, argv);
+    if (!a.dst || (!a.src && a.synthetic < 0)) {
+        if (!a.help) cli_help();
+        return a.help ? 0 : 1;
     }
-    /* destination defaults copy the source (hdr2yuv.cpp:265-318) */
-    if (!a.dst_w) a.dst_w = a.src_w;
-    if (!a.dst_h) a.dst_h = a.src_h;
-    if (a.src_chroma < 0) a.src_chroma = H2Y_CHROMA_444;
-    if (a.dst_chroma < 0) a.dst_chroma = a.src_chroma;
-    if (a.src_prim < 0) a.src_prim = 9;
-    if (a.dst_prim < 0) a.dst_prim = a.src_prim;
-    if (a.src_mat < 0) a.src_mat = H2Y_MATRIX_GBR;
-    if (a.dst_mat < 0) a.dst_mat = a.src_mat;
-    if (a.src_tr < 0) a.src_tr = H2Y_TRANSFER_LINEAR;
-    if (a.dst_tr < 0) a.dst_tr = a.src_tr;
-    if (a.src_full < 0) a.src_full = 1;
-    if (a.dst_full < 0) a.dst_full = a.src_full;
-
-    if (!a.dst || (!a.src && a.synthetic < 0)) { help(); return 1; }
-    if (strcasecmp(ext_of(a.dst), "yuv")) {
-        printf("ERROR: only .yuv output is on this path (TIFF/EXR/DPX writers stay with the reference host code)\n");
+    if (cli_resolve(a)) {
+        printf("TOO MANY ARGUMENT ERRORS. ABORTING PROGRAM. --help to show options\n\n"); /* hdr2yuv.cpp:567-572 (which exits 0) */
         return 1;
     }
-    if (a.dst_w != a.src_w || a.dst_h != a.src_h) {
+    if (a.out.width != a.in.width || a.out.height != a.in.height) {
         printf("ERROR: resizing is not part of convert() (cv.cpp is compiled out in the reference)\n");
         return 1;
     }
-    if (a.src_chroma != H2Y_CHROMA_444) {
-        printf("ERROR, matrix_convert(): input picture must be 4:4:4\n"); /* convert.cpp:886 */
-        return 1;
-    }
-
     h2y_desc d;
-    memset(&d, 0, sizeof d);
-    d.width = a.src_w;
-    d.height = a.src_h;
-    const char *ext = a.src ? ext_of(a.src) : "f32";
-    bool rgb_order = false;
-    if (a.synthetic >= 0) d.in_sample_type = a.src_half ? H2Y_SAMPLE_F16 : H2Y_SAMPLE_F32;
-    else if (!strcasecmp(ext, "f32")) d.in_sample_type = H2Y_SAMPLE_F32;
-    else if (!strcasecmp(ext, "f16")) d.in_sample_type = H2Y_SAMPLE_F16;
-    else if (!strcasecmp(ext, "yuv")) d.in_sample_type = H2Y_SAMPLE_U16;
-    else if (!strcasecmp(ext, "rgb")) { d.in_sample_type = H2Y_SAMPLE_U16; rgb_order = true; }
-    else {
-        printf("WARNING: input file (%s) type extension (%s) is either not recognized or not supported\n"
-               "         (.exr/.tiff/.dpx decoding stays with the reference's host I/O; this path takes raw planes)\n", a.src, ext);
-        return 1;
-    }
-    if (d.in_sample_type == H2Y_SAMPLE_U16 && !a.src_depth) a.src_depth = 16;
-    if (!a.dst_depth) a.dst_depth = d.in_sample_type == H2Y_SAMPLE_U16 ? a.src_depth : 10;
-    d.src_bit_depth = d.in_sample_type == H2Y_SAMPLE_U16 ? a.src_depth : 32;
-    d.dst_bit_depth = a.dst_depth;
-    d.src_transfer = a.src_tr;
-    d.dst_transfer = a.dst_tr;
-    d.src_matrix = a.src_mat;
-    d.dst_matrix = a.dst_mat;
-    d.src_primaries = a.src_prim;
-    d.dst_primaries = a.dst_prim;
-    d.dst_full_range = a.dst_full;
-    d.dst_chroma_format_idc = a.dst_chroma;
-    d.chroma_resampler_type = a.resampler;
-
-    const char *why = nullptr;
-    int rc = h2y_desc_check(&d, &why);
-    if (rc) { printf("ERROR: %s\n", why); return 1; }
-
-    h2y_ctx *ctx = nullptr;
-    rc = h2y_ctx_create(a.device, &ctx);
-    if (rc) { printf("ERROR: %s\n", h2y_last_error(nullptr)); return 1; }
-
-    const size_t n = (size_t)d.width * d.height, pb = h2y_plane_bytes(&d), ob = h2y_frame_bytes(&d);
-    FILE *fin = nullptr;
-    if (a.synthetic < 0) {
-        fin = fopen(a.src, "rb");
-        if (!fin) { printf("ERROR: unable to open file %s\n", a.src); return 1; }
-        if (fseek(fin, (long)((size_t)3 * pb * a.start_frame), SEEK_SET)) { printf("ERROR: seek failed\n"); return 1; }
-    }
-    FILE *fout = fopen(a.dst, "ab"); /* tiff.cpp:440: ios::ate | ios::app */
-    if (!fout) { printf("ERROR: unable to open %s\n", a.dst); return 1; }
-
-    /* The reader fills the pinned slot of the pipeline directly, the writer appends what comes out of
-     * it two frames later: upload, conversion and download of neighbouring frames overlap. */
-    const int depth = 3;
-    rc = h2y_stream_open(ctx, &d, depth);
-    if (rc) { printf("ERROR: %s\n", h2y_last_error(ctx)); return 1; }
-    int in_flight = 0, written = 0;
-    auto drain_one = [&]() -> int {
-        const uint16_t *yuv = nullptr;
-        if (h2y_stream_output(ctx, &yuv)) { printf("ERROR: %s\n", h2y_last_error(ctx)); return 1; }
-        if (fwrite(yuv, 1, ob, fout) != ob) { printf("ERROR: short write to %s\n", a.dst); return 1; }
-        if (a.verbose > 0) printf("frame %d: %zu bytes appended to %s\n", written, ob, a.dst);
-        written++;
-        in_flight--;
-        return 0;
-    };
-    for (int f = 0; f < (a.n_frames > 0 ? a.n_frames : 1); f++) {
-        void *planes[3];
-        if (h2y_stream_input(ctx, planes)) { printf("ERROR: %s\n", h2y_last_error(ctx)); return 1; }
-        if (fin) {
-            /* file plane order -> memory planes (0=G/Y, 1=B/Cb, 2=R/Cr) */
-            const int order_rgb[3] = {2, 0, 1}, order_nat[3] = {0, 1, 2};
-            const int *ord = rgb_order ? order_rgb : order_nat;
-            size_t got = 0;
-            for (int k = 0; k < 3; k++) got += fread(planes[ord[k]], 1, pb, fin);
-            if (got != 3 * pb) {
-                if (f == 0) { printf("ERROR: only %zu bytes read from %s, expecting %zu\n", got, a.src, 3 * pb); return 1; }
-                break;
-            }
-        } else {
-            uint32_t s = 12345u + (uint32_t)(a.synthetic + f);
-            for (int c = 0; c < 3; c++) {
-                for (size_t i = 0; i < n; i++) {
-                    s = s * 1664525u + 1013904223u;
-                    float v = (float)(s >> 8) * (1.0f / 16777216.0f);
-                    if (i == 0) v = 0.0f;
-                    if (i == 1) v = 1.0f;
-                    if (d.in_sample_type == H2Y_SAMPLE_F16) ((uint16_t *)planes[c])[i] = f32_to_f16(v);
-                    else ((float *)planes[c])[i] = v;
-                }
-            }
+    cli_make_desc(a, &d);
+    size_t in_frame_bytes, out_frame_bytes;
+    if (a.inverse) {
+        if (a.out.bit_depth > 16 || a.in.bit_depth > 16) { printf("ERROR: bit depths must be 8..16 on the inverse flow\n"); return 1; }
+        if (a.out.bit_depth < a.in.bit_depth) { /* tiff.cpp:564: SR = dst - src depth, then `R << SR` */
+            printf("ERROR: dst bit_depth(%d) < src bit_depth(%d): write_tiff() would shift by a negative count (undefined in the reference)\n", a.out.bit_depth, a.in.bit_depth);
+            return 1;
         }
-        if (h2y_stream_submit(ctx)) { printf("ERROR: %s\n", h2y_last_error(ctx)); return 1; }
-        in_flight++;
-        if (in_flight == depth - 1 && drain_one()) return 1;
+        const size_t n = (size_t)a.in.width * a.in.height;
+        const size_t nc = a.in.chroma_format_idc == H2Y_CHROMA_420 ? (size_t)(a.in.width / 2) * (a.in.height / 2) : n;
+        in_frame_bytes = (n + 2 * nc) * 2;
+        out_frame_bytes = 3 * n * 2;
+    } else {
+        const char *why = nullptr;
+        if (h2y_desc_check(&d, &why)) { printf("ERROR: %s\n", why); return 1; }
+        in_frame_bytes = 3 * h2y_plane_bytes(&d);
+        out_frame_bytes = h2y_frame_bytes(&d);
     }
-    while (in_flight > 0)
-        if (drain_one()) return 1;
-    h2y_stream_close(ctx);
-    if (fin) fclose(fin);
-    fclose(fout);
-    h2y_ctx_destroy(ctx);
-    return 0;
+
+    /* how many frames there are to do: --n_frames, or what the file holds from --src_start_frame on if that is fewer */
+    long frames = a.n_frames > 0 ? a.n_frames : 1;
+    struct stat st;
+    if (a.in_type != CLI_IN_SYNTH && !(a.dry_run && stat(a.src, &st))) { /* (a dry run may name a file that is not there) */
+        if (stat(a.src, &st)) { printf("ERROR: unable to open file %s\n", a.src); return 1; }
+        const long have = (long)((st.st_size - (off_t)in_frame_bytes * a.start_frame) / (off_t)in_frame_bytes);
+        if (st.st_size < (off_t)in_frame_bytes * (a.start_frame + 1)) {
+            printf("ERROR: only %lld bytes in %s, expecting %zu from frame %d on\n", (long long)st.st_size, a.src, in_frame_bytes, a.start_frame);
+            return 1;
+        }
+        if (frames > have) frames = have;
+    }
+    if (a.gpus < 1) a.gpus = 1;
+    if (a.devices.empty()) {
+        if (a.gpus == 1) a.devices.push_back(a.device);
+        else for (int r = 0; r < a.gpus; r++) a.devices.push_back(r);
+    }
+    if ((int)a.devices.size() != a.gpus) { printf("ERROR: --devices names %zu devices, --gpus %d\n", a.devices.size(), a.gpus); return 1; }
+    printf("gpus: %d (devices", a.gpus);
+    for (int dv : a.devices) printf(" %d", dv);
+    printf(")\nframes: %ld\nframe_bytes: %zu\n", frames, out_frame_bytes);
+    if (a.dry_run) return 0;
+
+    /* tiff.cpp:440 opens ios::ate | ios::app: what is in the file stays, frames go behind it */
+    int fd = open(a.dst, O_WRONLY | O_CREAT, 0644);
+    if (fd < 0) { printf("ERROR: unable to open %s\n", a.dst); return 1; }
+    const off_t base = lseek(fd, 0, SEEK_END);
+
+    /* contiguous blocks of frame indices, the first `frames % gpus` one longer (hdr2yuv_amd/shard.py) */
+    std::vector<block> blocks(a.gpus);
+    long at = 0;
+    for (int r = 0; r < a.gpus; r++) {
+        blocks[r].device = a.devices[r];
+        blocks[r].first = at;
+        blocks[r].count = frames / a.gpus + (r < frames % a.gpus ? 1 : 0);
+        at += blocks[r].count;
+    }
+    auto work = [&](block *b) { a.inverse ? run_block_inverse(a, fd, base, b) : run_block(a, d, fd, base, b); };
+    if (a.gpus == 1) work(&blocks[0]);
+    else {
+        std::vector<std::thread> th;
+        for (int r = 0; r < a.gpus; r++) th.emplace_back(work, &blocks[r]);
+        for (auto &t : th) t.join();
+    }
+    close(fd);
+    int rc = 0;
+    for (int r = 0; r < a.gpus; r++)
+        if (!blocks[r].err.empty()) {
+            printf("ERROR (device %d, frames %ld..%ld): %s\n", blocks[r].device, blocks[r].first, blocks[r].first + blocks[r].count - 1, blocks[r].err.c_str());
+            rc = 1;
+        }
+    return rc;
 }

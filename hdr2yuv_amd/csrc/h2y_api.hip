@@ -1539,6 +1539,40 @@ int h2y_inverse_420(h2y_ctx *ctx, int width, int height, int in_bit_depth, int i
     return h2y_matrix_inverse(ctx, width, height, in_bit_depth, in_full_range, in_matrix_coeffs, out_bit_depth, full, d_out);
 }
 
+int h2y_inverse_frame(h2y_ctx *ctx, int width, int height, int in_chroma_format_idc, int in_bit_depth, int in_full_range,
+                      int in_matrix_coeffs, int out_bit_depth, int algorithm, const uint16_t *const in_planes[3], uint16_t *const out_planes[3])
+{
+    if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
+    if ((ctx->q_count > 0) || ctx->streaming) return fail(ctx, H2Y_EINVAL, "a batch is pending or a stream is open");
+    if (in_chroma_format_idc != H2Y_CHROMA_444 && in_chroma_format_idc != H2Y_CHROMA_420)
+        return fail(ctx, H2Y_EUNSUPPORTED, "inverse flow: input chroma_format_idc must be 3 (4:4:4) or 1 (4:2:0)");
+    if (width < 1 || height < 1 || (uint64_t)width * height >= (1ull << 28)) return fail(ctx, H2Y_EINVAL, "bad picture size");
+    if (!in_planes || !out_planes) return fail(ctx, H2Y_EINVAL, "null pointer arrays");
+    for (int c = 0; c < 3; c++)
+        if (!in_planes[c] || !out_planes[c]) return fail(ctx, H2Y_EINVAL, "plane %d is null", c);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const bool sub = in_chroma_format_idc == H2Y_CHROMA_420;
+    const size_t pb = (size_t)width * height * sizeof(uint16_t), pb_al = (pb + 255) & ~(size_t)255;
+    const size_t cb = sub ? (size_t)(width >> 1) * (height >> 1) * sizeof(uint16_t) : pb;
+    int rc = ensure(ctx, ctx->d_in, ctx->in_cap, 3 * pb_al);
+    if (rc) return rc;
+    rc = ensure(ctx, ctx->d_out, ctx->out_cap, 3 * pb_al);
+    if (rc) return rc;
+    const uint16_t *din[3];
+    uint16_t *dout[3];
+    for (int c = 0; c < 3; c++) {
+        din[c] = reinterpret_cast<const uint16_t *>((char *)ctx->d_in + c * pb_al);
+        dout[c] = reinterpret_cast<uint16_t *>((char *)ctx->d_out + c * pb_al);
+        HIP_TRY(ctx, hipMemcpyAsync((void *)din[c], in_planes[c], c ? cb : pb, hipMemcpyHostToDevice, ctx->stream));
+    }
+    rc = sub ? h2y_inverse_420(ctx, width, height, in_bit_depth, in_full_range, in_matrix_coeffs, out_bit_depth, algorithm, din, dout)
+             : h2y_matrix_inverse(ctx, width, height, in_bit_depth, in_full_range, in_matrix_coeffs, out_bit_depth, din, dout);
+    if (rc) return rc;
+    for (int c = 0; c < 3; c++) HIP_TRY(ctx, hipMemcpyAsync(out_planes[c], dout[c], pb, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return H2Y_OK;
+}
+
 /* ---- streaming pipeline ------------------------------------------------------
  * H2D of frame k+1, conversion of frame k and D2H of frame k-1 overlap: three streams, a ring of
  * pinned host slots the caller fills and drains in place.  Every frame is converted in the

@@ -215,6 +215,15 @@ int h2y_upsample_444(h2y_ctx *ctx, int width, int height, int algorithm, unsigne
 int h2y_inverse_420(h2y_ctx *ctx, int width, int height, int in_bit_depth, int in_full_range, int in_matrix_coeffs,
                     int out_bit_depth, int algorithm, const uint16_t *const d_in[3], uint16_t *const d_out[3]);
 
+/* The same flow on HOST buffers, one frame: what main() does between read_planar_integer_file() (hdr2yuv.cpp:582-656) and
+ * write_tiff() (tiff.cpp:559-652: the `<< (out depth - in depth)` of its sample loop is part of out_bit_depth here) when a
+ * .yuv is read for a .tiff (hdr2yuv.cpp:818-819).  in_planes = Y, Cb/Dz, Cr/Dx as the file holds them: all three width x height
+ * for in_chroma_format_idc 3 (h2y_matrix_inverse), chroma at half size each way for 1 (h2y_inverse_420 with `algorithm`);
+ * out_planes = G, B, R, width x height each.  Copies in, runs the device path, copies out, synchronises. */
+int h2y_inverse_frame(h2y_ctx *ctx, int width, int height, int in_chroma_format_idc, int in_bit_depth, int in_full_range,
+                      int in_matrix_coeffs, int out_bit_depth, int algorithm, const uint16_t *const in_planes[3],
+                      uint16_t *const out_planes[3]);
+
 /* ---- host <-> device pipeline --------------------------------------------
  * The reference reads a frame, converts it and appends it to the .yuv, one after the other
  * (hdr2yuv.cpp:582-656 reader, :797-928, tiff.cpp:457-551 writer).  Here the upload of frame

@@ -89,6 +89,6 @@ def test_cli_built_and_fails_loudly_without_gpu():
     assert r.returncode == 0 and "--dst_matrix_coeffs" in r.stdout and "--chroma_resampler_type" in r.stdout
     if not torch.cuda.is_available():
         r = subprocess.run([exe, "--synthetic", "0", "--src_pic_width", "64", "--src_pic_height", "32", "--dst_filename",
-                            "/tmp/_h2y_never.yuv", "--dst_transfer_characteristics", "16", "--dst_matrix_coeffs", "9",
+                            "/tmp/_h2y_never.yuv", "--src_bit_depth", "32", "--dst_bit_depth", "10", "--src_transfer_characteristics", "8", "--dst_transfer_characteristics", "16", "--dst_matrix_coeffs", "9",
                             "--dst_chroma_format_idc", "1", "--dst_video_full_range_flag", "0"], capture_output=True, text=True)
         assert r.returncode == 1 and "no CPU path" in r.stdout

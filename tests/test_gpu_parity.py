@@ -342,7 +342,7 @@ def test_cli_writes_reference_bytes(tmp_path):
         subprocess.run(["make", "-C", os.path.join(root, "hdr2yuv_amd", "cli"), "--no-print-directory"], check=True)
     out = str(tmp_path / "o.yuv")
     cmd = [exe, "--synthetic", "0", "--src_pic_width", "64", "--src_pic_height", "32", "--dst_filename", out,
-           "--dst_bit_depth", "10", "--src_transfer_characteristics", "8", "--dst_transfer_characteristics", "16",
+           "--src_bit_depth", "32", "--dst_bit_depth", "10", "--src_transfer_characteristics", "8", "--dst_transfer_characteristics", "16",
            "--dst_matrix_coeffs", "9", "--dst_colour_primaries", "9", "--dst_chroma_format_idc", "1",
            "--dst_video_full_range_flag", "0", "--chroma_resampler_type", "1"]
     for n in (1, 2):
@@ -1189,7 +1189,7 @@ def test_cli_reads_raw_files(tmp_path, oracle):
     frames = [_rand_planes(rng, w, hh, h.SAMPLE_F32) for _ in range(2)]
     src, dst = tmp_path / "in.f32", tmp_path / "f32.yuv"
     src.write_bytes(b"".join(p.tobytes() for fr in frames for p in fr))
-    _cli(["--src_filename", src, "--dst_filename", dst, "--src_pic_width", w, "--src_pic_height", hh, "--n_frames", 2, "--dst_bit_depth", 10,
+    _cli(["--src_filename", src, "--dst_filename", dst, "--src_pic_width", w, "--src_pic_height", hh, "--n_frames", 2, "--src_bit_depth", 32, "--dst_bit_depth", 10,
           "--src_transfer_characteristics", 8, "--dst_transfer_characteristics", 16, "--dst_matrix_coeffs", 1, "--dst_chroma_format_idc", 1,
           "--dst_video_full_range_flag", 0])
     od = ob.make_desc(w, hh, dst_depth=10, dst_matrix=1, resampler=1)
@@ -1200,7 +1200,7 @@ def test_cli_reads_raw_files(tmp_path, oracle):
     hframes = [[p.astype(np.float16).view(np.uint16) for p in frames[0]]]
     src, dst = tmp_path / "in.f16", tmp_path / "f16.yuv"
     src.write_bytes(b"".join(p.tobytes() for fr in hframes for p in fr))
-    _cli(["--src_filename", src, "--dst_filename", dst, "--src_pic_width", w, "--src_pic_height", hh, "--dst_bit_depth", 12,
+    _cli(["--src_filename", src, "--dst_filename", dst, "--src_pic_width", w, "--src_pic_height", hh, "--src_bit_depth", 16, "--dst_bit_depth", 12,
           "--src_transfer_characteristics", 8, "--dst_transfer_characteristics", 16, "--dst_matrix_coeffs", 9, "--dst_chroma_format_idc", 1,
           "--dst_video_full_range_flag", 1, "--chroma_resampler_type", 0])
     od = ob.make_desc(w, hh, sample=ob.SAMPLE_F16, dst_depth=12, dst_matrix=9, resampler=0, full_range=1)
@@ -1211,8 +1211,8 @@ def test_cli_reads_raw_files(tmp_path, oracle):
     src, dst = tmp_path / "in.rgb", tmp_path / "rgb.yuv"
     src.write_bytes(r.tobytes() + g.tobytes() + b.tobytes())
     _cli(["--src_filename", src, "--dst_filename", dst, "--src_pic_width", w, "--src_pic_height", hh, "--src_bit_depth", 16, "--dst_bit_depth", 10,
-          "--src_transfer_characteristics", 16, "--dst_transfer_characteristics", 16, "--dst_matrix_coeffs", 9, "--dst_chroma_format_idc", 1,
-          "--src_video_full_range_flag", 0, "--chroma_resampler_type", 1])
+          "--src_transfer_characteristics", 16, "--dst_transfer_characteristics", 16, "--dst_matrix_coeffs", 9, "--src_chroma_format_idc", 3,
+          "--dst_chroma_format_idc", 1, "--src_video_full_range_flag", 0, "--chroma_resampler_type", 1])
     od = ob.make_desc(w, hh, sample=ob.SAMPLE_U16, src_depth=16, dst_depth=10, src_transfer=16, dst_transfer=16, dst_matrix=9, resampler=1)
     assert np.array_equal(np.fromfile(dst, np.uint16), oracle.convert_frame(od, [g, b, r]))
 
@@ -1223,12 +1223,117 @@ def test_cli_reads_raw_files(tmp_path, oracle):
     dst.write_bytes(b"\x01\x02" * 8)  # what is already there stays
     _cli(["--src_filename", src, "--dst_filename", dst, "--src_pic_width", w, "--src_pic_height", hh, "--src_bit_depth", 16, "--dst_bit_depth", 12,
           "--src_start_frame", 1, "--n_frames", 3, "--src_transfer_characteristics", 16, "--dst_transfer_characteristics", 16,
-          "--dst_matrix_coeffs", 11, "--dst_chroma_format_idc", 3, "--src_video_full_range_flag", 0])
+          "--dst_matrix_coeffs", 11, "--src_chroma_format_idc", 3, "--dst_chroma_format_idc", 3, "--src_video_full_range_flag", 0])
     od = ob.make_desc(w, hh, sample=ob.SAMPLE_U16, src_depth=16, dst_depth=12, src_transfer=16, dst_transfer=16, dst_matrix=11, chroma=3)
     got = dst.read_bytes()
     assert got[:16] == b"\x01\x02" * 8
     want = np.concatenate([oracle.convert_frame(od, yframes[k]) for k in (1, 2, 3)])
     assert np.array_equal(np.frombuffer(got[16:], np.uint16), want)
+
+
+def test_cli_runs_the_reference_test_sh_lines(tmp_path, oracle):
+    """test.sh:21-57 and :66-74 flag for flag (tests/cli_lines.py): no range flag anywhere, so the reference's destination is
+    VIDEO range (in_pic zeroed at hdr2yuv.cpp:765, copied to the destination at :296-297) -- also on the .exr line, where
+    read_exr() forces only the input picture to full range (exr.cpp:183).  Synthetic files of the lines' own sizes."""
+    from cli_lines import TEST_SH
+
+    rng = np.random.default_rng(2121)
+    w, hh = 2560, 1600
+    n = w * hh
+    planes = [rng.integers(0, 4096, n).astype(np.uint16) for _ in range(3)]
+    (tmp_path / "in.yuv").write_bytes(b"".join(p.tobytes() for p in planes))  # file order Y, Cb, Cr = planes 0,1,2
+    (tmp_path / "in.rgb").write_bytes(b"".join(p.tobytes() for p in planes))  # file order R, G, B = planes 2,0,1
+    for name, mem, od in (
+        ("yuv444_to_444", planes, ob.make_desc(w, hh, sample=ob.SAMPLE_U16, src_depth=12, dst_depth=12, src_transfer=1, dst_transfer=1, src_matrix=1,
+                                               dst_matrix=1, src_primaries=1, dst_primaries=1, full_range=0, chroma=3, resampler=1)),
+        ("yuv444_to_420", planes, ob.make_desc(w, hh, sample=ob.SAMPLE_U16, src_depth=12, dst_depth=12, src_transfer=1, dst_transfer=1, src_matrix=1,
+                                               dst_matrix=1, src_primaries=1, dst_primaries=1, full_range=0, chroma=1, resampler=1)),
+        ("rgb_to_420_10b", [planes[1], planes[2], planes[0]],
+         ob.make_desc(w, hh, sample=ob.SAMPLE_U16, src_depth=12, dst_depth=10, src_transfer=1, dst_transfer=1, src_matrix=0, dst_matrix=1,
+                      src_primaries=1, dst_primaries=1, full_range=0, chroma=1, resampler=1)),
+    ):
+        dst = tmp_path / (name + ".yuv")
+        _cli(TEST_SH[name].format(src=tmp_path / "in", dst=tmp_path / name).split())
+        assert np.array_equal(np.fromfile(dst, np.uint16), oracle.convert_frame(od, mem)), name
+    # the .exr line: half planes as read_exr() leaves them; LINEAR -> BT.709 (bt1886_r), 10-bit BT.709 4:2:0, video range
+    w, hh = 1920, 1080
+    half = [p.astype(np.float16).view(np.uint16) for p in _rand_planes(rng, w, hh, h.SAMPLE_F32)]
+    (tmp_path / "in.f16").write_bytes(b"".join(p.tobytes() for p in half))
+    _cli(TEST_SH["exr_to_420_10b"].format(src=tmp_path / "in", dst=tmp_path / "exr").split())
+    od = ob.make_desc(w, hh, sample=ob.SAMPLE_F16, dst_depth=10, src_transfer=8, dst_transfer=1, src_matrix=0, dst_matrix=1,
+                      src_primaries=1, dst_primaries=1, full_range=0, chroma=1, resampler=1)
+    assert np.array_equal(np.fromfile(tmp_path / "exr.yuv", np.uint16), oracle.convert_frame(od, half))
+
+
+def test_cli_default_range_is_the_reference_s(tmp_path, oracle):
+    """A float input with no range flag at all: video range out (235 x D scale, [16 D, 235 D] / [16 D, 240 D] clamps);
+    --src_video_full_range_flag 1 alone makes the destination full range (copied at parse time); an explicit
+    --dst_video_full_range_flag wins over both."""
+    rng = np.random.default_rng(99)
+    w, hh = 128, 32
+    frame = _rand_planes(rng, w, hh, h.SAMPLE_F32)
+    src = tmp_path / "in.f32"
+    src.write_bytes(b"".join(p.tobytes() for p in frame))
+    common = ["--src_filename", src, "--src_pic_width", w, "--src_pic_height", hh, "--src_bit_depth", 32, "--dst_bit_depth", 10,
+              "--src_transfer_characteristics", 8, "--dst_transfer_characteristics", 16, "--dst_matrix_coeffs", 9, "--dst_chroma_format_idc", 1]
+    for extra, full in (([], 0), (["--src_video_full_range_flag", 1], 1), (["--src_video_full_range_flag", 1, "--dst_video_full_range_flag", 0], 0)):
+        dst = tmp_path / f"o{len(extra)}.yuv"
+        _cli(common + ["--dst_filename", dst] + extra)
+        od = ob.make_desc(w, hh, dst_depth=10, dst_matrix=9, src_primaries=0, dst_primaries=0, resampler=1, full_range=full)
+        assert np.array_equal(np.fromfile(dst, np.uint16), oracle.convert_frame(od, frame)), extra
+
+
+def test_cli_frame_blocks_on_two_contexts(tmp_path, oracle):
+    """--gpus 2 (both contexts on device 0 here: --devices 0,0): two host threads, each with its own context and pinned
+    ring, frames 0..3 and 4..6 of seven; every frame lands at `old size + k x frame bytes`, so the file is what seven
+    appending runs would have left (tiff.cpp:440) and what the single-context run writes."""
+    rng = np.random.default_rng(4242)
+    w, hh, nf = 192, 48, 9
+    frames = [_rand_planes(rng, w, hh, h.SAMPLE_F32) for _ in range(nf)]
+    src = tmp_path / "in.f32"
+    src.write_bytes(b"".join(p.tobytes() for fr in frames for p in fr))
+    args = ["--src_filename", src, "--src_pic_width", w, "--src_pic_height", hh, "--src_bit_depth", 32, "--dst_bit_depth", 12,
+            "--src_transfer_characteristics", 8, "--dst_transfer_characteristics", 16, "--dst_matrix_coeffs", 9, "--dst_chroma_format_idc", 1,
+            "--src_start_frame", 1, "--n_frames", 7, "--chroma_resampler_type", 1]
+    one, two = tmp_path / "one.yuv", tmp_path / "two.yuv"
+    for path in (one, two):
+        path.write_bytes(b"\x07" * 10)  # what is already in the file stays in front
+    _cli(args + ["--dst_filename", one])
+    r = _cli(args + ["--dst_filename", two, "--gpus", 2, "--devices", "0,0", "--verbose_level", 1])
+    assert "frame 3:" in r.stdout and "frame 6:" in r.stdout
+    od = ob.make_desc(w, hh, dst_depth=12, dst_matrix=9, src_primaries=0, dst_primaries=0, resampler=1, full_range=0)
+    want = b"\x07" * 10 + np.concatenate([oracle.convert_frame(od, frames[k]) for k in range(1, 8)]).tobytes()
+    assert one.read_bytes() == want
+    assert two.read_bytes() == want
+
+
+def test_cli_inverse_flow_writes_planar_rgb(tmp_path, oracle, ctx):
+    """.yuv in, .rgb out: matrix_inverse() (hdr2yuv.cpp:818-819) with write_tiff()'s shift (tiff.cpp:564), the samples it
+    would interleave written as planes R, G, B; test.sh:78-86's flags (12-bit BT.709 4:4:4 -> 16 bits), and a 4:2:0 file
+    through the upsampler first (yuv2tiff.cpp:341-342).  h2y_inverse_frame is the host-buffer entry underneath."""
+    rng = np.random.default_rng(8686)
+    w, hh = 256, 64
+    n = w * hh
+    y, cb, cr = [rng.integers(0, 4096, n).astype(np.uint16) for _ in range(3)]
+    src, dst = tmp_path / "in.yuv", tmp_path / "out.rgb"
+    src.write_bytes(y.tobytes() + cb.tobytes() + cr.tobytes())
+    _cli(("--src_matrix_coeffs 1 --dst_matrix_coeffs 0 --src_transfer_characteristics 1 --dst_transfer_characteristics 1 "
+          f"--src_colour_primaries 1 --dst_colour_primaries 1 --src_filename {src} --dst_filename {dst} "
+          f"--src_pic_width {w} --src_pic_height {hh} --src_bit_depth 12 --dst_bit_depth 16 "
+          "--src_chroma_format_idc 3 --dst_chroma_format_idc 3 --verbose_level 4 --src_start_frame 0").split())
+    g, b, r = oracle.matrix_inverse(w, hh, 12, 0, 1, 16, [y, cb, cr])
+    assert np.array_equal(np.fromfile(dst, np.uint16), np.concatenate([r, g, b]))
+    got = ctx.inverse_frame(w, hh, 3, 12, 0, 1, 16, 0, [y, cb, cr])
+    assert all(np.array_equal(a, b_) for a, b_ in zip(got, (g, b, r)))
+    # 4:2:0 input, Y'DzDx, FIR upsampler
+    cb2, cr2 = cb[: n // 4], cr[: n // 4]
+    src.write_bytes(y.tobytes() + cb2.tobytes() + cr2.tobytes())
+    dst = tmp_path / "out2.rgb"
+    _cli(["--src_filename", src, "--dst_filename", dst, "--src_pic_width", w, "--src_pic_height", hh, "--src_bit_depth", 12, "--dst_bit_depth", 16,
+          "--src_matrix_coeffs", 11, "--src_chroma_format_idc", 1, "--dst_chroma_format_idc", 3, "--chroma_resampler_type", 1])
+    full = [y, oracle.up444(cb2, w, hh, 1, 0, 4095).reshape(-1), oracle.up444(cr2, w, hh, 1, 0, 4095).reshape(-1)]
+    g, b, r = oracle.matrix_inverse(w, hh, 12, 0, 11, 16, full)
+    assert np.array_equal(np.fromfile(dst, np.uint16), np.concatenate([r, g, b]))
 
 
 def test_context_options_and_variant_names(oracle):

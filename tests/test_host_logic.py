@@ -125,3 +125,69 @@ def test_bench_refuses_fewer_gpus_than_asked():
     assert r.returncode != 0 and out is None and "refusing" in r.stderr
     r, out = _run_bench(["--gpus", "1", "--rehearse"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and out is None and "refusing" in r.stderr
+
+
+# ---- the command line: how unset attributes resolve (hdr2yuv.cpp:61-62, :265-318, :765-766; read_file) -------------
+
+def _cli_dry(args):
+    import subprocess
+
+    exe = os.path.join(ROOT, "hdr2yuv_amd", "hdr2yuv")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "hdr2yuv_amd", "cli"), "--no-print-directory"], check=True)
+    r = subprocess.run([exe] + [str(a) for a in args] + ["--dry_run", "1"], capture_output=True, text=True)
+    kv = {}
+    for ln in r.stdout.splitlines():
+        if ": " in ln and not ln.startswith(("WARNING", "ERROR")):
+            k, v = ln.split(": ", 1)
+            kv[k] = v
+    return r, kv
+
+
+from cli_lines import TEST_SH  # noqa: E402
+
+
+def test_cli_resolves_test_sh_lines_like_the_reference(tmp_path):
+    """No range flag on any line: in_pic is zeroed (hdr2yuv.cpp:765) so the source range is 0, and the destination copies
+    it at parse time (:296-297) -- VIDEO range out, also for the .exr line, where read_exr() forces only the INPUT picture
+    to full range afterwards (exr.cpp:183)."""
+    for name, line in TEST_SH.items():
+        r, kv = _cli_dry(line.format(src=tmp_path / "in", dst=tmp_path / "out").split())
+        assert r.returncode == 0, r.stdout
+        assert kv["dst_video_full_range_flag"] == "0", name
+        assert kv["src_colour_primaries"] == kv["dst_colour_primaries"] == "1"
+        assert kv["chroma_resampler_type"] == "1"  # SURVEY Q14: uninitialised in the reference; FIR here
+    assert kv["src_full_range_video_flag"] == "0"  # printed before read_exr() would run, as in the reference (:478)
+
+
+def test_cli_unset_attributes_are_zero_and_dst_copies_src(tmp_path):
+    base = ["--src_filename", tmp_path / "a.f32", "--dst_filename", tmp_path / "o.yuv", "--src_pic_width", 64, "--src_pic_height", 32]
+    # nothing but geometry and a depth: everything 0, dst depth <- src depth, dst chroma <- the src value AS PARSED (0),
+    # while the float input itself is then set to 4:4:4 (hdr2yuv.cpp:351-355)
+    r, kv = _cli_dry(base + ["--src_bit_depth", 16])
+    assert r.returncode != 0 and "dst_chroma_format_idc must be" in r.stdout  # 0 = mono: resolved as the reference does, not on this path
+    for k in ("src_full_range_video_flag", "src_colour_primaries", "src_transfer_characteristics", "src_matrix_coeffs",
+              "dst_video_full_range_flag", "dst_colour_primaries", "dst_transfer_characteristics", "dst_matrix_coeffs", "dst_chroma_format_idc"):
+        assert kv[k] == "0", k
+    assert kv["dst_bit_depth"] == "16" and kv["src_chroma_format_idc"] == "3"
+    # dst <- src when only the source is given; an explicit dst wins
+    r, kv = _cli_dry(base + ["--src_bit_depth", 16, "--src_video_full_range_flag", 1, "--src_colour_primaries", 9,
+                             "--src_transfer_characteristics", 8, "--src_matrix_coeffs", 0, "--dst_transfer_characteristics", 16,
+                             "--src_chroma_format_idc", 3, "--dst_chroma_format_idc", 1, "--dst_bit_depth", 10])
+    assert (kv["dst_video_full_range_flag"], kv["dst_colour_primaries"], kv["dst_transfer_characteristics"], kv["dst_matrix_coeffs"],
+            kv["dst_chroma_format_idc"], kv["dst_bit_depth"]) == ("1", "9", "16", "0", "1", "10")
+    # no --src_bit_depth: "src bit_depth(0) outside range [8,32]" -> too many argument errors (hdr2yuv.cpp:531-534)
+    r, kv = _cli_dry(base)
+    assert r.returncode != 0 and "TOO MANY ARGUMENT ERRORS" in r.stdout and "src bit_depth(0)" in r.stdout
+    # integer input without --src_chroma_format_idc: "Only 4:4:4 input supported" (hdr2yuv.cpp:539-543)
+    r, kv = _cli_dry(["--src_filename", tmp_path / "a.yuv", "--dst_filename", tmp_path / "o.yuv", "--src_pic_width", 64,
+                      "--src_pic_height", 32, "--src_bit_depth", 12])
+    assert r.returncode != 0 and "Only 4:4:4 input supported" in r.stdout
+    # a codec format names where its decoder lives instead of guessing
+    r, kv = _cli_dry(["--src_filename", tmp_path / "a.exr", "--dst_filename", tmp_path / "o.yuv", "--src_pic_width", 64,
+                      "--src_pic_height", 32, "--src_bit_depth", 16])
+    assert r.returncode != 0 and "exr.cpp" in r.stdout
+    # --gpus: the frame blocks of hdr2yuv_amd/shard.py
+    r, kv = _cli_dry(["--synthetic", 0, "--dst_filename", tmp_path / "o.yuv", "--src_pic_width", 64, "--src_pic_height", 32, "--src_bit_depth", 32,
+                      "--dst_bit_depth", 10, "--dst_chroma_format_idc", 1, "--dst_matrix_coeffs", 9, "--n_frames", 7, "--gpus", 3])
+    assert r.returncode == 0 and kv["gpus"] == "3 (devices 0 1 2)" and kv["frames"] == "7" and kv["frame_bytes"] == "6144"

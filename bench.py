@@ -69,6 +69,8 @@ def parse(argv=None):
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements (other resampler, C1/C3/C4)")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames for the CPU baseline sample (0 = auto ~15 s)")
     ap.add_argument("--lib", default=None, help="load this build of libhdr2yuv_hip.so instead of the in-tree one (recorded in the JSON)")
+    ap.add_argument("--allow-experiment", action="store_true", help="with --lib: accept a -DH2Y_EXPERIMENT build (timing variants that may write wrong "
+                                                                     "bytes); the JSON line then says experiment_build: true and verified: false")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="h2y_ctx_set_option knobs (A/B timing), e.g. fir=twopass")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (nccl = RCCL; gloo only to rehearse N > 1)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
@@ -90,16 +92,35 @@ def parse(argv=None):
 # ---------------------------------------------------------------------------------------------
 # N > 1 from a plain `python bench.py --gpus N`: this process only launches the ranks
 # ---------------------------------------------------------------------------------------------
+def visible_gpus():
+    """GPUs this process tree would see, counted WITHOUT any HIP / torch call: the entries of the visibility variables when
+    one is set, else the KFD topology nodes that have SIMDs (CPU nodes have none).  None when neither is readable."""
+    for var in ("HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            return len([x for x in v.split(",") if x.strip() != ""])
+    top = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(top):
+            with open(os.path.join(top, node, "properties")) as f:
+                props = dict(ln.split()[:2] for ln in f if len(ln.split()) >= 2)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+        return n
+    except OSError:
+        return None
+
+
 def launch_ranks(args) -> int:
-    """Parent of the N ranks.  Never makes a HIP call (torch.cuda.device_count() does not initialise the GPU
-    on this image); the ranks are fresh processes started by torch.distributed.run."""
+    """Parent of the N ranks.  Never makes a HIP call -- it does not even import torch: the devices are counted from the
+    environment / sysfs (visible_gpus) -- and the ranks are fresh processes started by torch.distributed.run.  Where the
+    count cannot be read the ranks decide: each refuses to run without its own device."""
     n = args.gpus
     if not args.rehearse:
-        import torch
-
-        have = torch.cuda.device_count()
+        have = visible_gpus()
         need = 1 if args.share_gpu else n
-        if have < need:
+        if have is not None and have < need:
             print(f"[bench] --gpus {n} asked for but only {have} GPU(s) visible: refusing to measure fewer silently", file=sys.stderr)
             return 2
     s = socket.socket()
@@ -189,7 +210,9 @@ def run_steps(ctx, d, n_frames, ins, outs, steps, warmup, barrier, pipeline=True
 def cpu_baseline(desc_kw, resampler, n_frames_hint):
     """The reference CPU path timed on this box's host cores, single thread (the
     reference is single-threaded): oracle/_ref (the reference's own object code)
-    when that prebuilt library travelled with the repo, else our C restatement."""
+    when that prebuilt library travelled with the repo, else our C restatement.
+    Converts frames 0, 1, ... (seed 12345 + k each) and keeps the md5 of every .yuv
+    frame it produced: ({figures}, {frame index: md5})."""
     from hdr2yuv_amd.synth import synth_frame
     from oracle import binding as ob
 
@@ -204,47 +227,57 @@ def cpu_baseline(desc_kw, resampler, n_frames_hint):
     kw["resampler"] = 1 if resampler == "fir" else 0
     od = ob.make_desc(**kw)
     w, h = kw["width"], kw["height"]
-    planes = synth_frame(w, h, 0, f16=kw.get("sample") == 3)
+    f16 = kw.get("sample") == 3
+    md5s = {}
+    planes = synth_frame(w, h, 0, f16=f16)
     t0 = time.perf_counter()
-    impl.convert_frame(od, planes)
+    md5s[0] = hashlib.md5(impl.convert_frame(od, planes).tobytes()).hexdigest()
     one = time.perf_counter() - t0
     n = n_frames_hint or max(1, min(8, int(15.0 / max(one, 1e-3))))
+    inputs = [synth_frame(w, h, k, f16=f16) for k in range(n)]
     t0 = time.perf_counter()
-    for k in range(n):
-        impl.convert_frame(od, planes)
+    outs = [impl.convert_frame(od, planes) for planes in inputs]
     dt = time.perf_counter() - t0
+    for k, o in enumerate(outs):
+        md5s[k] = hashlib.md5(o.tobytes()).hexdigest()
     return {
         "value": round(n * w * h / dt / 1e6, 3),
         "unit": "Mpixels/s",
         "cores": 1,
         "kind": kind,
-        "sample": f"{n} frame(s) of the same {w}x{h} workload ({resampler}), {dt:.1f} s, single thread, "
+        "sample": f"frames 0..{n - 1} of the same {w}x{h} workload ({resampler}), {dt:.1f} s, single thread, "
                   f"pic_stats+matrix_convert+convert+write_yuv arithmetic",
-    }
+    }, md5s
 
 
-def cpu_baseline_parallel(desc_kw, resampler, frames_each=2):
-    """Frame-parallel run of the same CPU path: one single-threaded process per host core, each converting
-    `frames_each` frames (SURVEY 8d asks for both figures; the reference itself is one process per frame)."""
+def cpu_baseline_parallel(desc_kw, resampler, indices):
+    """Frame-parallel run of the same CPU path: one single-threaded process per host core, the frames `indices` dealt
+    round-robin between them (SURVEY 8d asks for both figures; the reference itself is one process per frame).
+    ({figures}, {frame index: md5}) or (None, {})."""
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = max(1, min(cores, 16))  # a one-GPU box's CPU share is 16 cores, whatever the affinity mask says
+    cores = max(1, min(cores, 16, len(indices)))  # a one-GPU box's CPU share is 16 cores, whatever the affinity mask says
     kw = dict(desc_kw)
-    if kw.get("sample") == 3 or kw.get("chroma", 1) != 1:
-        return None  # the helper script covers the fp32 4:2:0 workloads
-    cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), str(kw["width"]), str(kw["height"]), str(frames_each),
-           "1" if resampler == "fir" else "0", str(kw["dst_depth"]), str(kw["dst_matrix"])]
+    if kw.get("sample") == 3 or kw.get("chroma", 1) != 1 or not indices:
+        return None, {}  # the helper script covers the fp32 4:2:0 workloads
+    base = [sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), str(kw["width"]), str(kw["height"]),
+            "1" if resampler == "fir" else "0", str(kw["dst_depth"]), str(kw["dst_matrix"])]
     t0 = time.perf_counter()
-    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for _ in range(cores)]
+    procs = [subprocess.Popen(base + [str(k) for k in indices[c::cores]], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for c in range(cores)]
     kinds = set()
+    md5s = {}
     for p in procs:
-        out, _ = p.communicate(timeout=600)
+        out, _ = p.communicate(timeout=900)
         if p.returncode != 0:
-            return None
-        kinds.add(out.split()[0])
+            return None, {}
+        lines = out.splitlines()
+        kinds.add(lines[0].split()[0])
+        for ln in lines[1:]:
+            tag, k, digest = ln.split()
+            md5s[int(k)] = digest
     dt = time.perf_counter() - t0  # includes the start-up of the processes: a lower bound of the rate
-    return {"value": round(cores * frames_each * kw["width"] * kw["height"] / dt / 1e6, 2), "unit": "Mpixels/s", "cores": cores,
+    return {"value": round(len(indices) * kw["width"] * kw["height"] / dt / 1e6, 2), "unit": "Mpixels/s", "cores": cores,
             "kind": "reference" if kinds == {"reference"} else "port",
-            "sample": f"{cores} processes x {frames_each} frame(s), {dt:.1f} s wall including process start-up"}
+            "sample": f"{cores} processes, {len(indices)} distinct frames between them, {dt:.1f} s wall including process start-up"}, md5s
 
 
 def sources_sha256():
@@ -322,7 +355,7 @@ def main() -> int:
     from hdr2yuv_amd.shard import frames_for_rank
 
     if args.lib:
-        h_api.set_library_path(args.lib)
+        h_api.set_library_path(args.lib, allow_experiment=args.allow_experiment)
     if args.share_gpu:
         if args.backend != "gloo":
             print("[bench] --share-gpu needs --backend gloo", file=sys.stderr)
@@ -374,9 +407,10 @@ def main() -> int:
         arena = torch.empty(len(indices) * 3 * n, dtype=torch.float16 if f16 else torch.float32, device=dev)
         return [synth_cache[key].frame(w, hh, k, f16, into=[arena[(i * 3 + c) * n:(i * 3 + c + 1) * n] for c in range(3)]) for i, k in enumerate(indices)]
 
-    def measure(wl, resampler, frames_in, F, steps, warmup):
+    def measure(wl, resampler, frames_in, F, steps, warmup, check=()):
         """One timed pass of workload `wl` over F frames per step (frames_in may hold fewer DISTINCT inputs: they repeat;
-        every frame has its own output).  Returns a dict of figures; all ranks call it together."""
+        every frame has its own output).  Returns a dict of figures; all ranks call it together.  `check`: output frames whose
+        md5 rank 0 takes after the timed loop (r["md5_frames"]), to be held against the CPU reference's frames of the same index."""
         desc_kw, bytes_per_px, wl_name, stem = WORKLOADS[wl]
         is420 = desc_kw.get("chroma", 1) == 1
         w, hh = desc_kw["width"], desc_kw["height"]
@@ -410,6 +444,11 @@ def main() -> int:
             if want:
                 got_md5 = hashlib.md5(outs_t[0].cpu().numpy().tobytes()).hexdigest()
                 verified = got_md5 == want
+        md5_frames = {}
+        if rank == 0 and args.content == "uniform":
+            for f in check:
+                if 0 <= f < F and f < len(frames_in):  # (output f was made from the generator's frame f)
+                    md5_frames[f] = hashlib.md5(outs_t[f].cpu().numpy().tobytes()).hexdigest()
         del outs_t
         alg_bytes = bytes_per_px * w * hh * F  # per step
         ach_kernel = alg_bytes / (kernel_ms / 1e3) / 1e9 if kernel_ms > 0 else 0.0
@@ -417,7 +456,7 @@ def main() -> int:
         return dict(workload=wl, text=wl_name, resampler=resampler if is420 else "none", is420=is420, secs=tmax, pixels=total_px, steps=steps,
                     per_rank=[float(t[1]) / float(t[0]) / 1e6 for t in allr], kernel_ms=kernel_ms, launches=launches, redone=redone,
                     kernel=kernel, variant=variant, verified=verified, verify_case=vname, md5=got_md5, alg_bytes=alg_bytes,
-                    ach_kernel=ach_kernel, ach_wall=ach_wall, w=w, h=hh, frames=F, per_step=per_step)
+                    ach_kernel=ach_kernel, ach_wall=ach_wall, w=w, h=hh, frames=F, per_step=per_step, md5_frames=md5_frames)
 
     def roofline_of(r, traffic=None, traffic_source=None):
         """Dominant kernel of the pass.  Box / 4:4:4 and the fused FIR path run ONE kernel per launch: `achieved` is its
@@ -429,7 +468,11 @@ def main() -> int:
                "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                "timed_by": "wall time of a step (two kernels on two streams)" if two_pass else "HIP events around the kernel, on its stream",
                "algorithmic_bytes_per_launch": r["alg_bytes"] / max(r["launches"], 1), "launches_per_step": r["launches"],
-               "kernel_ms_per_step": round(r["kernel_ms"], 4)}
+               "kernel_ms_per_step": round(r["kernel_ms"], 4),
+               # every timed step's kernel time: where the allocator put this run's planes moves the mean by 3-10 % from one process to
+               # the next while the steps of ONE run agree to about 1 % -- a wide spread here means something else
+               "kernel_ms_min_max": [round(min(r["per_step"]), 4), round(max(r["per_step"]), 4)] if r["per_step"] else None,
+               "kernel_ms_spread": round((max(r["per_step"]) - min(r["per_step"])) / (sum(r["per_step"]) / len(r["per_step"])), 4) if r["per_step"] else None}
         return out
 
     # ---- main measurement -----------------------------------------------------------------
@@ -471,7 +514,12 @@ def main() -> int:
     except Exception:
         copy_gbs = None
 
-    main_r = measure(args.workload, args.resampler, frames_in, F, args.steps, args.warmup)
+    # frames whose bytes are compared with the CPU reference's (N = 1): 0..7 (the single-thread baseline converts those anyway) and 32
+    # more spread over the rest of the batch, the last one included (the frame-parallel baseline converts those): both frame groups,
+    # every block's slice range, the first and the last launch split
+    do_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline
+    check = sorted(set(range(min(8, F))) | {8 + (i * (F - 9)) // 31 for i in range(32) if F > 9}) if do_cpu and args.content == "uniform" else []
+    main_r = measure(args.workload, args.resampler, frames_in, F, args.steps, args.warmup, check)
     value = main_r["pixels"] / main_r["secs"] / 1e6
     ms_per_step = main_r["secs"] / args.steps * 1e3
 
@@ -499,11 +547,17 @@ def main() -> int:
         "frames_per_s": round(value * 1e6 / (w * hh), 1),
         "per_rank_mpixels_s": [round(v, 1) for v in main_r["per_rank"]],
         "verified": main_r["verified"],
-        "verify": {"case": main_r["verify_case"], "md5": main_r["md5"], "what": "md5 of rank 0's output frame 0 after the timed loop vs tests/golden/known_md5.json"},
+        "verified_frames": [],
+        "verify": {"case": main_r["verify_case"], "md5": main_r["md5"],
+                   "what": "md5 of rank 0's output frame 0 after the timed loop vs tests/golden/known_md5.json; verified_frames: output frames whose md5 "
+                           "equals the CPU reference's frame of the same index, converted in this run (cpu_baseline)"},
         "library": {"path": os.path.relpath(lib_path, ROOT) if lib_path.startswith(ROOT) else lib_path, "sha256": lib_sha,
                     "sources_sha256": sources_sha256()},
         "options": args.option,
     }
+    if h_api.is_experiment_build():  # only reachable with --lib ... --allow-experiment
+        out["experiment_build"] = True
+        out["verified"] = False
     traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, TRAFFIC_FILE)
     if os.path.exists(tpath):
@@ -525,6 +579,7 @@ def main() -> int:
     # ---- secondary passes (N = 1): the other resampler and the other BASELINE configs -------
     if world == 1 and not args.no_extra:
         others = {}
+        other_md5 = {}
         sec_steps, sec_warm = max(10, args.steps // 2), max(8, args.warmup)  # (the XCD weights settle within the first few launches)
         plan = []
         if is420:
@@ -543,8 +598,11 @@ def main() -> int:
                 ndist = nf  # every frame of a step its own input (8K: 16 x 199 MB; four inputs read four times each let frame groups
                             # that happened to read the same planes at the same time hit in the caches: 0.72 instead of 0.67)
                 fin = device_frames(kw2, range(ndist))
-            r = measure(wl, res, fin, nf, sec_steps, sec_warm)
             key = wl if WORKLOADS[wl][0].get("chroma", 1) != 1 else f"{wl}_{res}"
+            chk = check if (wl == args.workload and nf == F) else []
+            r = measure(wl, res, fin, nf, sec_steps, sec_warm, chk)
+            if chk:
+                other_md5[key] = (res, r["md5_frames"])
             rf = roofline_of(r)
             others[key] = {"value": round(r["pixels"] / r["secs"] / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(r["secs"] / r["steps"] * 1e3, 4),
                            "frames_per_step": nf, "distinct_input_frames": len(fin), "steps": r["steps"], "kernel": r["kernel"], "variant": r["variant"],
@@ -562,12 +620,33 @@ def main() -> int:
             out["fir_value"] = others[f"{args.workload}_fir"]["value"]
             out["fir_ms_per_step"] = others[f"{args.workload}_fir"]["ms_per_step"]
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if do_cpu:
+        def compare(gpu_md5, cpu_md5):
+            both = sorted(set(gpu_md5) & set(cpu_md5))
+            return [k for k in both if gpu_md5[k] == cpu_md5[k]], [k for k in both if gpu_md5[k] != cpu_md5[k]]
+
         try:
-            out["cpu_baseline"] = cpu_baseline(desc_kw, args.resampler, args.cpu_frames)
-            par = cpu_baseline_parallel(desc_kw, args.resampler)
+            out["cpu_baseline"], cpu_md5 = cpu_baseline(desc_kw, args.resampler, args.cpu_frames)
+            par, par_md5 = cpu_baseline_parallel(desc_kw, args.resampler, [k for k in check if k not in cpu_md5])
             if par:
                 out["cpu_baseline_all_cores"] = par
+                cpu_md5.update(par_md5)
+            good, bad = compare(main_r["md5_frames"], cpu_md5)
+            out["verified_frames"] = good
+            if bad:
+                out["verified"] = False
+                out["verify"]["mismatched_frames"] = bad
+                failed = True
+            for key, (res, gmd5) in (other_md5 if world == 1 and not args.no_extra else {}).items():
+                par, par_md5 = cpu_baseline_parallel(desc_kw, res, sorted(gmd5))
+                good, bad = compare(gmd5, par_md5)
+                out["others"][key]["verified_frames"] = good
+                if par:
+                    out["others"][key]["cpu_baseline_all_cores"] = par
+                if bad:
+                    out["others"][key]["verified"] = False
+                    out["others"][key]["mismatched_frames"] = bad
+                    failed = True
         except Exception as e:  # the baseline is a reported number, never a reason to lose the GPU line
             out["cpu_baseline"] = {"value": None, "unit": "Mpixels/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
     ctx.close()

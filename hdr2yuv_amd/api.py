@@ -80,13 +80,24 @@ def library_path() -> str:
     return _LIB_PATH
 
 
-def set_library_path(path: str) -> None:
+ABI_VERSION = 1
+ABI_EXPERIMENT = 0x40000000  # H2Y_ABI_EXPERIMENT: a -DH2Y_EXPERIMENT build (timing variants, may write wrong bytes)
+_ALLOW_EXPERIMENT = False
+
+
+def set_library_path(path: str, allow_experiment: bool = False) -> None:
     """Load another build of the same library (tuning experiments: bench.py --lib, tools/).  Explicit, never from the
-    environment; must be called before the first load_library()."""
-    global _LIB_PATH
+    environment; must be called before the first load_library().  A timing-experiment build (h2y_abi_version() carries
+    H2Y_ABI_EXPERIMENT) is refused unless allow_experiment."""
+    global _LIB_PATH, _ALLOW_EXPERIMENT
     if _LIB is not None:
         raise RuntimeError("the library is already loaded")
     _LIB_PATH = os.path.abspath(path)
+    _ALLOW_EXPERIMENT = allow_experiment
+
+
+def is_experiment_build() -> bool:
+    return bool(load_library().h2y_abi_version() & ABI_EXPERIMENT)
 
 
 def build_library(force: bool = False) -> str:
@@ -117,6 +128,11 @@ def load_library():
         raise FileNotFoundError(f"{path} not built: run hdr2yuv_amd.build_library() (needs hipcc)")
     L = C.CDLL(path)
     L.h2y_abi_version.restype = C.c_int
+    ver = L.h2y_abi_version()
+    if ver & ABI_EXPERIMENT and not _ALLOW_EXPERIMENT:
+        raise RuntimeError(f"{path} is a timing-experiment build (-DH2Y_EXPERIMENT): its kernels may write wrong bytes; refused")
+    if ver & ~ABI_EXPERIMENT != ABI_VERSION:
+        raise RuntimeError(f"{path}: ABI version {ver & ~ABI_EXPERIMENT}, this binding is for {ABI_VERSION}")
     L.h2y_frame_bytes.restype = C.c_size_t
     L.h2y_frame_bytes.argtypes = [C.POINTER(H2YDesc)]
     L.h2y_plane_bytes.restype = C.c_size_t

@@ -788,7 +788,12 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
                 HIP_TRY(ctx, hipHostGetDevicePointer((void **)&ctx->b->hd_ranges, ctx->b->h_ranges, 0));
             }
             if (r.size() > kRangeWords) return fail(ctx, H2Y_EINVAL, "internal: %zu slice ranges", r.size());
-            if (sub == 0) ctx->b->slot_busy[0] = ctx->b->slot_busy[1] = false; /* the batch that last used this state has finished */
+            /* The kernels read these tables IN PLACE from mapped pinned memory: a slot may only be rewritten once every launch that
+             * reads it has finished.  A batch_state is handed out again only after its batch was finished (enqueue / finish,
+             * h2y_convert_frame), so both slots are free at a batch's first launch -- except on the stream pipeline, which calls
+             * run_frames() back to back on one state without synchronising: there the slots stay busy until the third-table
+             * path below has waited for the stream. */
+            if (sub == 0 && !ctx->streaming) ctx->b->slot_busy[0] = ctx->b->slot_busy[1] = false;
             int slot = -1;
             for (int k = 0; k < 2 && slot < 0; k++)
                 if (ctx->b->range_slot[k] == r) slot = k;
@@ -979,7 +984,14 @@ int run_stats(h2y_ctx *ctx, const h2y_desc *d, const void *const in[3], int slot
 
 extern "C" {
 
-int h2y_abi_version(void) { return H2Y_ABI_VERSION; }
+int h2y_abi_version(void)
+{
+#ifdef H2Y_EXPERIMENT
+    return H2Y_ABI_VERSION | H2Y_ABI_EXPERIMENT;
+#else
+    return H2Y_ABI_VERSION;
+#endif
+}
 
 int h2y_desc_check(const h2y_desc *d, const char **why)
 {

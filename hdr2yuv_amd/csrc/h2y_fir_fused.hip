@@ -437,6 +437,11 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
             if (PIPE == H2Y_PIPE_PQ_IDENT && a.low_flag && low_m != 0) a.low_flag[f] = 1u;
         }
     }
+    /* NO BARRIER MAY FOLLOW THE UNIT LOOP.  The pacing s_barrier inside the step loop is executed a different number of times by
+     * each wave (units of different length; waves without a unit leave at once): that is outside the HIP programming model and
+     * works because gfx950's barrier counts only the waves of the block that have not ended, and because nothing after the loop
+     * waits on one.  A __syncthreads() here would pair with another wave's pacing barrier (wrong hand-over) or never complete.
+     * tests/test_gpu_parity.py::test_fir_fused_kernel_geometries (blocks whose units differ in length) is the guard. */
     if (a.block_clock && (threadIdx.x & (WAVE - 1)) == 0) atomicMax(&a.block_clock[2 * blockIdx.x + 1], (unsigned long long)wall_clock64());
 #ifdef H2Y_BLOCK_TIMES
     if ((threadIdx.x & (WAVE - 1)) == 0) atomicMax(&g_ff_block_times[2 * blockIdx.x + 1], (unsigned long long)wall_clock64());

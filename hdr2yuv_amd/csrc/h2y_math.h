@@ -31,6 +31,17 @@
 #ifndef H2Y_MATH_H
 #define H2Y_MATH_H
 
+/* Timing-experiment variants of the kernels (some write WRONG BYTES, some dump block clocks and read an environment variable)
+ * compile only in a build that declares itself one: `make EXTRA="-DH2Y_EXPERIMENT -DH2Y_EXP_NOCOMPUTE=1"`.  Such a library reports
+ * H2Y_ABI_VERSION | H2Y_ABI_EXPERIMENT from h2y_abi_version(): hdr2yuv_amd/api.py, tests/test_abi.py and bench.py refuse it unless told
+ * `--allow-experiment` (and then say so in their output). */
+#if defined(H2Y_EXP_NOCOMPUTE) || defined(H2Y_HALF_COMPUTE) || defined(H2Y_SKIP_REDO) || defined(H2Y_EXP_NOSTATS) || defined(H2Y_EXP_NOCONFLICT) || \
+    defined(H2Y_BLOCK_TIMES)
+#ifndef H2Y_EXPERIMENT
+#error "timing-experiment variant requested without -DH2Y_EXPERIMENT: this would build a product library with wrong bytes or debug output"
+#endif
+#endif
+
 #include <stdint.h>
 #include <vector>
 

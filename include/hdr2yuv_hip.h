@@ -32,6 +32,8 @@ extern "C" {
 #endif
 
 #define H2Y_ABI_VERSION 1
+/* set in h2y_abi_version() by a timing-experiment build of the library (-DH2Y_EXPERIMENT: its kernels may write wrong bytes) */
+#define H2Y_ABI_EXPERIMENT 0x40000000
 
 /* ---- enums: integer values are the reference's CLI contract ------------ */
 

@@ -92,3 +92,19 @@ def test_cli_built_and_fails_loudly_without_gpu():
                             "/tmp/_h2y_never.yuv", "--src_bit_depth", "32", "--dst_bit_depth", "10", "--src_transfer_characteristics", "8", "--dst_transfer_characteristics", "16", "--dst_matrix_coeffs", "9",
                             "--dst_chroma_format_idc", "1", "--dst_video_full_range_flag", "0"], capture_output=True, text=True)
         assert r.returncode == 1 and "no CPU path" in r.stdout
+
+
+def test_experiment_variants_need_the_experiment_flag():
+    """Timing variants that write wrong bytes (-DH2Y_EXP_NOCOMPUTE, -DH2Y_SKIP_REDO, ...) do not compile into a product
+    library by accident: without -DH2Y_EXPERIMENT the preprocessor stops; with it h2y_abi_version() carries
+    H2Y_ABI_EXPERIMENT and the Python binding refuses the library."""
+    hdr = os.path.join(ROOT, "hdr2yuv_amd", "csrc", "h2y_math.h")
+    for flag in ("-DH2Y_EXP_NOCOMPUTE=1", "-DH2Y_HALF_COMPUTE", "-DH2Y_SKIP_REDO", "-DH2Y_EXP_NOSTATS", "-DH2Y_EXP_NOCONFLICT", "-DH2Y_BLOCK_TIMES"):
+        r = subprocess.run(["g++", "-E", "-x", "c++", flag, hdr, "-o", os.devnull], capture_output=True, text=True)
+        assert r.returncode != 0 and "H2Y_EXPERIMENT" in r.stderr, flag
+        r = subprocess.run(["g++", "-E", "-x", "c++", flag, "-DH2Y_EXPERIMENT", hdr, "-o", os.devnull], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-500:]
+    from hdr2yuv_amd import api
+
+    assert h.load_library().h2y_abi_version() == api.ABI_VERSION  # the in-tree build is a product build
+    assert not api.is_experiment_build()

@@ -59,7 +59,7 @@ const double kT1DenseShare = 0.08; /* T1 costs ~1.6x more per redone tile, k_fus
 /* A probe of the first tier on dense content is dear (letterboxed 4K, a quarter of the tiles flagged: 8.6 ms per 64-frame launch
  * against k_fused2's 1.6), staying on the binary64 tier too long is cheap (2-10 % slower than the first tier on content that
  * suits it): probe rarely -- after 32 batches, then 64, ... 1024. */
-const double kFirSyncMaxFlagged = 0.001; /* k_fir_fused: tiles-of-eight share of unsettled pixels above which its waves are left out of step */
+const double kFirSyncMaxFlagged = 0.004; /* k_fir_fused: tiles-of-eight share of unsettled pixels above which its waves are left out of step */
 const int kT1SkipBatches = 32;
 const int kT1SkipBatchesMax = 1024;
 const int kFirSubBatch = 32; /* frames per fused launch on the FIR path: every launch pays its table staging and its last redo pass */
@@ -1085,13 +1085,10 @@ static int ctx_init(h2y_ctx *ctx, int device)
         HIP_TRY(ctx, hipMemcpy(t, A.data(), H2Y_PQ_NREC * 16, hipMemcpyHostToDevice));
         HIP_TRY(ctx, hipMemcpy(t + H2Y_PQ_NREC * 16, B.data(), H2Y_PQ_NREC * 16, hipMemcpyHostToDevice));
         {
-            std::vector<pq_recA> XA(H2Y_PQX_NSEG);
-            std::vector<pq_recB> XB(H2Y_PQX_NSEG);
-            pq_build_table_ext(XA.data(), XB.data());
+            std::vector<pq_ext_rec> X(H2Y_PQX_NSEG);
+            pq_build_table_ext(X.data());
             HIP_TRY(ctx, hipMalloc(&ctx->d_table_ext, H2Y_PQX_TABLE_BYTES));
-            char *x = static_cast<char *>(ctx->d_table_ext);
-            HIP_TRY(ctx, hipMemcpy(x, XA.data(), H2Y_PQX_NSEG * 16, hipMemcpyHostToDevice));
-            HIP_TRY(ctx, hipMemcpy(x + H2Y_PQX_NSEG * 16, XB.data(), H2Y_PQX_NSEG * 16, hipMemcpyHostToDevice));
+            HIP_TRY(ctx, hipMemcpy(ctx->d_table_ext, X.data(), H2Y_PQX_TABLE_BYTES, hipMemcpyHostToDevice));
         }
         std::vector<pq_rec1> T1(H2Y_T1_NREC);
         pq_build_table1(T1.data());

@@ -246,6 +246,67 @@ __device__ __attribute__((noinline)) ycc pixel_careful(const pix_params *spp /* 
     return o;
 }
 
+/* PQ10000_r of the samples the LDS tables do not reach -- normal floats below 2^-24: dark pictures that never went through
+ * half floats hold them (a frame of squared uniform noise: 0.024 % of its samples) --, answered IN LINE from the table over
+ * every normal float below 2 in global memory (pq_build_table_ext, 254 KB, L2-resident), one flagged lane at a time: the
+ * lane's sample is read into a scalar register, its two 16-byte records fetched by SCALAR loads and the polynomial run on
+ * them.  Scalar loads count on lgkmcnt: the wave does not wait for its outstanding picture loads (vmcnt), which is what made
+ * the out-of-line careful tier cost ~5 us per such pixel inside the loops with a rolling prefetch (k_fir_fused on that
+ * frame: 2.39 ms against 1.76).  `slow` in: the LDS tier's verdict; out: still unsettled (ambiguous rounding, subnormal,
+ * negative, NaN, >= 2: the careful tier as before). */
+typedef const __attribute__((address_space(4))) uint32_t *h2y_const_u32;
+__device__ __forceinline__ float pq_ext_inline(float x, float v, bool &slow, const void *ext)
+{
+    const uint32_t xb = f2bits(x);
+    /* candidates: flagged, and 2^-126 <= x < 2^-24 (in the LDS table's own domain a flag means an ambiguous rounding,
+     * which the same polynomial would only repeat) */
+    const bool cand = slow && (xb - 0x00800000u) < (((uint32_t)(127 + H2Y_PQ_EMIN) << 23) - 0x00800000u);
+    uint64_t m = __builtin_amdgcn_ballot_w64(cand);
+    if (__builtin_expect(m != 0 && ext != nullptr, 0)) {
+        const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        const uint64_t base = reinterpret_cast<uint64_t>(ext);
+        do {
+            const uint32_t l = (uint32_t)__builtin_ctzll(m);
+            m &= m - 1;
+            const uint32_t bits = __builtin_amdgcn_readlane(xb, l);
+            const uint32_t idx = (bits >> H2Y_PQ_LOW_BITS) - H2Y_PQX_SEG_BASE;
+            const h2y_const_u32 pr = reinterpret_cast<h2y_const_u32>(base + (uint64_t)idx * 32u); /* pq_ext_rec: one s_load_dwordx8 */
+            const uint32_t w0 = pr[0], w1 = pr[1], w2 = pr[2], w3 = pr[3], w4 = pr[4], w5 = pr[5], w6 = pr[6], w7 = pr[7];
+            pq_recA a;
+            pq_recB b;
+            a.c0 = bits2d((uint64_t)w0 | ((uint64_t)w1 << 32));
+            a.c1 = bits2d((uint64_t)w2 | ((uint64_t)w3 << 32));
+            b.c2 = bits2d((uint64_t)w4 | ((uint64_t)w5 << 32));
+            b.c3 = bits2f(w6);
+            b.c4 = bits2f(w7);
+            const double d = pq_poly(bits, a, b);
+            const bool mine = lane == l;
+            v = mine ? (float)d : v;
+            slow = mine ? pq_ambiguous(d) : slow;
+        } while (m);
+    }
+    return v;
+}
+
+/* The same for code that has no picture loads in flight (k_fused_t1's redo passes, k_fused): every candidate lane reads ITS record
+ * with two 16-byte vector loads -- one latency for the wave however many lanes hold such a sample (a redo pass over a dark
+ * picture has several per pixel position, which the scalar form would take one after the other). */
+__device__ __forceinline__ float pq_ext_gather(float x, float v, bool &slow, const void *ext)
+{
+    const uint32_t xb = f2bits(x);
+    const bool cand = slow && (xb - 0x00800000u) < (((uint32_t)(127 + H2Y_PQ_EMIN) << 23) - 0x00800000u);
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(cand) != 0 && ext != nullptr, 0)) {
+        const uint32_t idx = cand ? (xb >> H2Y_PQ_LOW_BITS) - H2Y_PQX_SEG_BASE : 0u;
+        const pq_ext_rec *X = reinterpret_cast<const pq_ext_rec *>(ext);
+        const pq_recA a = X[idx].a;
+        const pq_recB b = X[idx].b;
+        const double d = pq_poly(xb, a, b);
+        v = cand ? (float)d : v;
+        slow = cand ? pq_ambiguous(d) : slow;
+    }
+    return v;
+}
+
 /* one stage of a transfer pair by the careful tier (h2y_math.h), out of line: what the table tier of the generic pairs
  * falls back to for a single sample */
 static __device__ __attribute__((noinline)) float tf_to_linear_careful(int cls, float v) { return tf_to_linear(cls, v); }
@@ -308,9 +369,15 @@ __device__ __forceinline__ bool pixel_fast(const pix_params &pp, const pq_recA *
         r = pix_scale(v[2], pp.mulC, pp.addC);
     } else if (conv) {
         bool sg, sb, sr;
-        g = pix_scale(pq_fast(G, sA, sB, &sg), pp.mulY, pp.addY);
-        b = pix_scale(pq_fast(B, sA, sB, &sb), pp.mulC, pp.addC);
-        r = pix_scale(pq_fast(R, sA, sB, &sr), pp.mulC, pp.addC);
+        float vg = pq_fast(G, sA, sB, &sg), vb = pq_fast(B, sA, sB, &sb), vr = pq_fast(R, sA, sB, &sr);
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(sg | sb | sr) != 0, 0)) { /* samples below the LDS table: in line, from the full-range table */
+            vg = pq_ext_gather(G, vg, sg, pp.pq_ext);
+            vb = pq_ext_gather(B, vb, sb, pp.pq_ext);
+            vr = pq_ext_gather(R, vr, sr, pp.pq_ext);
+        }
+        g = pix_scale(vg, pp.mulY, pp.addY);
+        b = pix_scale(vb, pp.mulC, pp.addC);
+        r = pix_scale(vr, pp.mulC, pp.addC);
         unsure = sg | sb | sr;
     }
     bool um;

@@ -340,10 +340,34 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
                     const uint64_t fm = __builtin_amdgcn_ballot_w64(ra) | __builtin_amdgcn_ballot_w64(rb);
                     if (__builtin_expect(fm != 0, 0)) {
                         /* some lane's pixel here is not settled: the binary64 tier for this pixel position, all lanes
-                         * together (no memory operation in this branch but LDS reads) */
+                         * together (no memory operation in this branch but LDS reads and -- samples below the tables -- scalar
+                         * loads).  Only the planes that hold an unsure sample of a flagged lane go through it: a sample the first
+                         * tier was sure of IS the reference's float, and most unsettled pixels have one unsure sample, not three */
                         uint32_t Y2, Cb2, Cr2;
                         const bool fl = ((fm >> lane) & 1u) != 0;
-                        const bool un = pixel_fast<MODE, PIPE>(pp, sA, sB, Gn, Bn, Rn, Y2, Cb2, Cr2);
+                        float g2 = g, b2 = b, r2 = rr;
+                        bool un = false;
+                        if (__builtin_amdgcn_ballot_w64(fl & ug) != 0) {
+                            bool sl;
+                            const float t = pq_ext_inline(Gn, pq_fast(Gn, sA, sB, &sl), sl, pp.pq_ext);
+                            g2 = (fl & ug) ? pix_scale(t, pp.mulY, pp.addY) : g2;
+                            un |= fl & ug & sl;
+                        }
+                        if (__builtin_amdgcn_ballot_w64(fl & ub) != 0) {
+                            bool sl;
+                            const float t = pq_ext_inline(Bn, pq_fast(Bn, sA, sB, &sl), sl, pp.pq_ext);
+                            b2 = (fl & ub) ? pix_scale(t, pp.mulC, pp.addC) : b2;
+                            un |= fl & ub & sl;
+                        }
+                        if (__builtin_amdgcn_ballot_w64(fl & ur) != 0) {
+                            bool sl;
+                            const float t = pq_ext_inline(Rn, pq_fast(Rn, sA, sB, &sl), sl, pp.pq_ext);
+                            r2 = (fl & ur) ? pix_scale(t, pp.mulC, pp.addC) : r2;
+                            un |= fl & ur & sl;
+                        }
+                        bool um;
+                        pix_matrix<MODE, false>(pp, g2, b2, r2, Y2, Cb2, Cr2, &um);
+                        un |= um;
                         if (__builtin_expect(fl & un, 0)) {
                             const ycc k = pixel_careful<MODE>(&s_pp, Gn, Bn, Rn);
                             Y2 = k.y; Cb2 = k.cb; Cr2 = k.cr;

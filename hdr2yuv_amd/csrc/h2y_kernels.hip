@@ -428,8 +428,11 @@ __device__ __forceinline__ float pq_sample(const pix_params &pp, int c, float ra
     const float x = norm1<PIPE>(pp, c, raw);
     bool slow;
     float v = pq_fast(x, sA, sB, &slow);
-    if (__builtin_expect(slow, 0)) v = pq_slow(x, *s_ext);
-    any_slow |= slow;
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(slow) != 0, 0)) {
+        v = pq_ext_inline(x, v, slow, *s_ext); /* below the LDS table: the full-range table by scalar loads, no wait for the prefetch */
+        if (slow) v = pq_slow(x, *s_ext);
+    }
+    any_slow |= slow; /* through pq_slow(): the value may be NaN */
     return pix_scale(v, c == 0 ? pp.mulY : pp.mulC, c == 0 ? pp.addY : pp.addC);
 }
 /* the same from a record already fetched (x normalised) */
@@ -439,9 +442,13 @@ __device__ __forceinline__ float pq_sample_rec(const pix_params &pp, int c, floa
     float v = pq_eval(x, rec, &sl);
     const bool zero = f2bits(x) == 0u; /* as pq_fast(): +0.0 is outside the table but its value is a constant */
     const bool slow = sl & !zero;
+    bool slow2 = slow;
     v = zero ? bits2f(H2Y_PQ_AT_ZERO_BITS) : v;
-    if (__builtin_expect(slow, 0)) v = pq_slow(x, *s_ext);
-    any_slow |= slow;
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(slow) != 0, 0)) {
+        v = pq_ext_inline(x, v, slow2, *s_ext);
+        if (slow2) v = pq_slow(x, *s_ext);
+    }
+    any_slow |= slow2; /* through pq_slow(): the value may be NaN */
     return pix_scale(v, c == 0 ? pp.mulY : pp.mulC, c == 0 ? pp.addY : pp.addC);
 }
 template <int IN_KIND, int OUT_KIND, int MODE, int PIPE>

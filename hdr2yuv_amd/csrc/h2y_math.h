@@ -619,15 +619,29 @@ inline void pq_build_table(pq_recA *A, pq_recB *B)
 #define H2Y_PQX_EMIN (-126)
 #define H2Y_PQX_NSEG ((1 - H2Y_PQX_EMIN) * H2Y_PQ_SEG_PER_BINADE)
 #define H2Y_PQX_SEG_BASE ((uint32_t)(127 + H2Y_PQX_EMIN) << H2Y_PQ_SEG_BITS)
-#define H2Y_PQX_TABLE_BYTES (H2Y_PQX_NSEG * 32) /* pq_recA[NSEG], then pq_recB[NSEG] */
-inline void pq_build_table_ext(pq_recA *A, pq_recB *B) { pq_build_segments(A, B, H2Y_PQX_EMIN, H2Y_PQX_NSEG); }
+#define H2Y_PQX_TABLE_BYTES (H2Y_PQX_NSEG * 32) /* one 32-byte record per segment: pq_recA, then pq_recB (pq_ext_rec) */
+struct alignas(32) pq_ext_rec { /* interleaved, so that one 32-byte scalar load fetches a segment (pq_ext_inline, h2y_device.h) */
+    pq_recA a;
+    pq_recB b;
+};
+inline void pq_build_table_ext(pq_ext_rec *X)
+{
+    pq_recA *A = new pq_recA[H2Y_PQX_NSEG];
+    pq_recB *B = new pq_recB[H2Y_PQX_NSEG];
+    pq_build_segments(A, B, H2Y_PQX_EMIN, H2Y_PQX_NSEG);
+    for (int i = 0; i < H2Y_PQX_NSEG; i++) {
+        X[i].a = A[i];
+        X[i].b = B[i];
+    }
+    delete[] A;
+    delete[] B;
+}
 H2Y_FN bool pq_ext_try(float x, const void *ext, float *v)
 {
     const uint32_t bits = f2bits(x), idx = (bits >> H2Y_PQ_LOW_BITS) - H2Y_PQX_SEG_BASE; /* subnormal: wraps high; >= 2, negative, NaN: high */
     if (idx >= (uint32_t)H2Y_PQX_NSEG) return false;
-    const pq_recA *A = reinterpret_cast<const pq_recA *>(ext);
-    const pq_recB *B = reinterpret_cast<const pq_recB *>(A + H2Y_PQX_NSEG);
-    const double d = pq_poly(bits, A[idx], B[idx]);
+    const pq_ext_rec *X = reinterpret_cast<const pq_ext_rec *>(ext);
+    const double d = pq_poly(bits, X[idx].a, X[idx].b);
     *v = (float)d;
     return !pq_ambiguous(d);
 }

@@ -1231,6 +1231,45 @@ def test_cli_reads_raw_files(tmp_path, oracle):
     assert np.array_equal(np.frombuffer(got[16:], np.uint16), want)
 
 
+@pytest.mark.parametrize("path", ["t1_box", "t2_box", "fir_fused"])
+def test_dark_frames_dense_below_the_tables(oracle, path):
+    """Whole frames of dark samples -- uniform noise to the fourth power: 1.6 % of the samples below 2^-24, every wave meets
+    several per tile row -- through the kernels that answer them in line from the full-range table by scalar loads
+    (pq_ext_inline): k_fused_t1's redo passes, k_fused2's sample step, k_fir_fused's binary64 branch."""
+    import torch
+
+    rng = np.random.default_rng(4444)
+    w, hh, n = 512, 128, 6
+    host = []
+    for k in range(n):
+        planes = [(rng.random(w * hh, dtype=np.float32) ** 4).astype(np.float32) for _ in range(3)]
+        for p in planes:
+            p[0], p[1] = 0.0, 1.0
+        host.append(planes)
+    kw = dict(dst_depth=12, dst_matrix=h.MATRIX_BT2020NC, resampler=1 if path == "fir_fused" else 0)
+    d = h.make_desc(w, hh, **kw)
+    od = _to_oracle_desc(d)
+    want = [oracle.convert_frame(od, fr) for fr in host]
+    c = h.Context(0)
+    try:
+        if path == "t2_box":
+            c.set_option("t1", "0")
+        if path == "fir_fused":
+            c.set_option("fir", "fused")
+        dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in host]
+        for rnd in range(2):
+            dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda") for _ in host]
+            torch.cuda.synchronize()
+            c.convert_batch(d, dev_in, dev_out)
+            if rnd == 0:
+                assert c.last_kernel_name() == {"t1_box": "k_fused_t1", "t2_box": "k_fused2", "fir_fused": "k_fir_fused"}[path], c.last_kernel_variant()
+            for f in range(n):
+                got = dev_out[f].cpu().numpy().view(np.uint16)
+                assert np.array_equal(got, want[f]), (path, rnd, f, int(np.count_nonzero(got != want[f])))
+    finally:
+        c.close()
+
+
 def test_cli_runs_the_reference_test_sh_lines(tmp_path, oracle):
     """test.sh:21-57 and :66-74 flag for flag (tests/cli_lines.py): no range flag anywhere, so the reference's destination is
     VIDEO range (in_pic zeroed at hdr2yuv.cpp:765, copied to the destination at :296-297) -- also on the .exr line, where

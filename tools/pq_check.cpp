@@ -213,8 +213,8 @@ int main(int argc, char **argv)
         uint32_t lo = (uint32_t)strtoul(argv[2], 0, 0), hi = (uint32_t)strtoul(argv[3], 0, 0);
         int T = argc > 4 ? atoi(argv[4]) : 8;
         uint64_t stride = argc > 5 ? strtoull(argv[5], 0, 0) : 1;
-        std::vector<pq_recA> X(2 * H2Y_PQX_NSEG);
-        pq_build_table_ext(X.data(), reinterpret_cast<pq_recB *>(X.data() + H2Y_PQX_NSEG));
+        std::vector<pq_ext_rec> X(H2Y_PQX_NSEG);
+        pq_build_table_ext(X.data());
         std::atomic<uint64_t> mism{0}, ntab{0}, maxerr{0}, total{0};
         std::vector<std::thread> th;
         uint64_t span = (uint64_t)hi - lo;
@@ -231,7 +231,7 @@ int main(int argc, char **argv)
                     if (pq_ext_try(x, X.data(), &tv)) {
                         nt++;
                         const uint32_t idx = ((uint32_t)u >> H2Y_PQ_LOW_BITS) - H2Y_PQX_SEG_BASE;
-                        const double v = pq_poly((uint32_t)u, X[idx], reinterpret_cast<const pq_recB *>(X.data() + H2Y_PQX_NSEG)[idx]);
+                        const double v = pq_poly((uint32_t)u, X[idx].a, X[idx].b);
                         const int64_t d = (int64_t)(d2bits(v) - d2bits(vref));
                         const uint64_t ad = d < 0 ? -d : d;
                         if (ad > me) me = ad;

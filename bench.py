@@ -54,7 +54,12 @@ WORKLOADS = {
     "C1": (dict(width=1920, height=1080, dst_depth=10, dst_matrix=1), 15.0,
            "1920x1080 fp32 RGB -> PQ -> 10-bit BT.709 YCbCr 4:2:0", "C1_1080p_709_10b"),
 }
-TRAFFIC_FILE = os.path.join("profiles", "r02_pmc_traffic.json")
+# the other transfer pairs of the same dispatch point (convert.cpp:1024-1109) on the C2 picture and output format
+TF_PAIRS = {"tf_linear_to_bt709": (8, 1, 1), "tf_pq_to_linear": (16, 8, 1), "tf_bt709_to_pq": (1, 16, 2), "tf_pq_to_bt709": (16, 1, 2)}  # src, dst, stages
+for _name, (_s, _d, _n) in TF_PAIRS.items():
+    WORKLOADS[_name] = (dict(width=3840, height=2160, dst_depth=12, dst_matrix=9, src_transfer=_s, dst_transfer=_d), 15.0,
+                        f"3840x2160 fp32 RGB, transfer {_s} -> {_d} ({_n} table stage{'s' if _n > 1 else ''}) -> 12-bit BT.2020nc YCbCr 4:2:0", None)
+TRAFFIC_FILE = os.path.join("profiles", "r03_pmc_traffic.json")
 
 
 def parse(argv=None):
@@ -259,8 +264,11 @@ def cpu_baseline_parallel(desc_kw, resampler, indices):
     kw = dict(desc_kw)
     if kw.get("sample") == 3 or kw.get("chroma", 1) != 1 or not indices:
         return None, {}  # the helper script covers the fp32 4:2:0 workloads
-    base = [sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py"), str(kw["width"]), str(kw["height"]),
-            "1" if resampler == "fir" else "0", str(kw["dst_depth"]), str(kw["dst_matrix"])]
+    base = [sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py")]
+    for key in ("src_transfer", "dst_transfer"):
+        if key in kw:
+            base += ["--" + key.replace("_", "-"), str(kw[key])]
+    base += [str(kw["width"]), str(kw["height"]), "1" if resampler == "fir" else "0", str(kw["dst_depth"]), str(kw["dst_matrix"])]
     t0 = time.perf_counter()
     procs = [subprocess.Popen(base + [str(k) for k in indices[c::cores]], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True) for c in range(cores)]
     kinds = set()
@@ -293,6 +301,8 @@ def sources_sha256():
 
 
 def known_md5(stem, is420, resampler):
+    if stem is None:
+        return "none (no known answer: compared with the CPU reference's frames of this run)", None
     name = stem if not is420 else f"{stem}_{resampler}"
     with open(os.path.join(ROOT, "tests", "golden", "known_md5.json")) as f:
         case = json.load(f)["cases"].get(name)
@@ -589,6 +599,9 @@ def main() -> int:
                 plan.append((wl, "box", nf))
         if args.workload != "C4":
             plan.append(("C4", "fir", 16))
+        if args.workload == "C2":
+            for name in TF_PAIRS:
+                plan.append((name, "box", F))
         for wl, res, nf in plan:
             kw2 = WORKLOADS[wl][0]
             same_input = (kw2["width"], kw2["height"], kw2.get("sample", 2)) == (w, hh, desc_kw.get("sample", 2))
@@ -598,11 +611,17 @@ def main() -> int:
                 ndist = nf  # every frame of a step its own input (8K: 16 x 199 MB; four inputs read four times each let frame groups
                             # that happened to read the same planes at the same time hit in the caches: 0.72 instead of 0.67)
                 fin = device_frames(kw2, range(ndist))
-            key = wl if WORKLOADS[wl][0].get("chroma", 1) != 1 else f"{wl}_{res}"
-            chk = check if (wl == args.workload and nf == F) else []
+            key = wl if (WORKLOADS[wl][0].get("chroma", 1) != 1 or wl in TF_PAIRS) else f"{wl}_{res}"
+            chk = check if (wl == args.workload and nf == F) else ([0, 1, nf - 1] if wl in TF_PAIRS and do_cpu else [])
             r = measure(wl, res, fin, nf, sec_steps, sec_warm, chk)
+            hiccup = None
+            if r["per_step"] and max(r["per_step"]) > 3.0 * sorted(r["per_step"])[len(r["per_step"]) // 2]:
+                # one launch of the pass took several times the others (seen once in a few runs, on the first timed launch after a pass
+                # allocated gigabytes: 25 ms against 0.9): not the kernel's speed.  The pass is measured again, the first try reported
+                hiccup = [round(x, 3) for x in r["per_step"]]
+                r = measure(wl, res, fin, nf, sec_steps, sec_warm, chk)
             if chk:
-                other_md5[key] = (res, r["md5_frames"])
+                other_md5[key] = (res, r["md5_frames"], WORKLOADS[wl][0])
             rf = roofline_of(r)
             others[key] = {"value": round(r["pixels"] / r["secs"] / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(r["secs"] / r["steps"] * 1e3, 4),
                            "frames_per_step": nf, "distinct_input_frames": len(fin), "steps": r["steps"], "kernel": r["kernel"], "variant": r["variant"],
@@ -610,11 +629,48 @@ def main() -> int:
                            "kernel_ms_steps": [round(x, 3) for x in r["per_step"]] if r["per_step"] and max(r["per_step"]) > 1.5 * min(r["per_step"]) else None,
                            "frames_redone": r["redone"], "achieved_gbs": rf["achieved"], "timed_by": rf["timed_by"], "bytes_per_pixel": WORKLOADS[wl][1],
                            "verified": r["verified"], "verify_case": r["verify_case"], "workload": r["text"] + (f", chroma {res}" if r["is420"] else "")}
+            if hiccup:
+                others[key]["measured_again_after_kernel_ms_steps"] = hiccup
             failed = failed or r["verified"] is False
             if fin is not frames_in:
                 del fin
                 # (no torch.cuda.empty_cache() here: returning gigabytes to the driver in the middle of the run was followed, one
                 # run in eight, by a single 12-18 ms launch in the NEXT pass -- the card has 288 GB, the blocks stay cached)
+        # the .yuv 4:2:0 -> RGB flow (h2y_inverse_420: Subsample420to444 of both chroma planes + matrix_inverse in one
+        # kernel), one 4K frame per call as the entry takes it: 12-bit BT.709 in, 16-bit G,B,R planes out, FIR upsampler
+        try:
+            import numpy as np
+
+            rng = np.random.default_rng(420)
+            n = w * hh
+            host = [rng.integers(0, 4096, n if c == 0 else n // 4, dtype=np.uint16) for c in range(3)]
+            din = [torch.from_numpy(p.view(np.int16)).to(dev) for p in host]
+            dout = [torch.zeros(n, dtype=torch.int16, device=dev) for _ in range(3)]
+            torch.cuda.synchronize()
+            times = []
+            for k in range(5 + sec_steps):
+                ctx.inverse_420(w, hh, 12, 0, 1, 16, 1, din, dout)
+                if k >= 5:
+                    times.append(ctx.last_kernel_ms()[0])
+            ms = sum(times) / len(times)
+            inv = {"value": round(n / ms / 1e3, 1), "unit": "Mpixels/s", "kernel": ctx.last_kernel_name(), "variant": ctx.last_kernel_variant(),
+                   "kernel_ms_per_frame": round(ms, 5), "kernel_ms_min_max": [round(min(times), 5), round(max(times), 5)], "bytes_per_pixel": 9.0,
+                   "achieved_gbs": round(9.0 * n / ms / 1e6, 1), "frac": round(9.0 * n / ms / 1e6 / HBM_PEAK_GBS, 4), "frames_per_call": 1,
+                   "workload": "3840x2160 12-bit BT.709 Y'CbCr 4:2:0 -> 16-bit G,B,R planes (Subsample420to444 FIR + matrix_inverse)",
+                   "timed_by": "HIP events around the kernel, on its stream", "verified": None}
+            if do_cpu:
+                from oracle import binding as ob
+
+                orc = ob.Oracle()
+                full = [host[0], orc.up444(host[1], w, hh, 1, 0, 4095).reshape(-1), orc.up444(host[2], w, hh, 1, 0, 4095).reshape(-1)]
+                want = orc.matrix_inverse(w, hh, 12, 0, 1, 16, full)
+                inv["verified"] = all(np.array_equal(dout[c].cpu().numpy().view(np.uint16), want[c]) for c in range(3))
+                inv["verify_case"] = "all three output planes against the oracle's Subsample420to444 + matrix_inverse of the same frame"
+                failed = failed or not inv["verified"]
+            others["inverse_420"] = inv
+            del din, dout
+        except Exception as e:  # a secondary figure never costs the main line
+            others["inverse_420"] = {"value": None, "error": str(e)}
         out["others"] = others
         if is420 and args.resampler == "box" and f"{args.workload}_fir" in others:  # round-1 field names, kept
             out["fir_value"] = others[f"{args.workload}_fir"]["value"]
@@ -637,10 +693,12 @@ def main() -> int:
                 out["verified"] = False
                 out["verify"]["mismatched_frames"] = bad
                 failed = True
-            for key, (res, gmd5) in (other_md5 if world == 1 and not args.no_extra else {}).items():
-                par, par_md5 = cpu_baseline_parallel(desc_kw, res, sorted(gmd5))
+            for key, (res, gmd5, okw) in (other_md5 if world == 1 and not args.no_extra else {}).items():
+                par, par_md5 = cpu_baseline_parallel(okw, res, sorted(gmd5))
                 good, bad = compare(gmd5, par_md5)
                 out["others"][key]["verified_frames"] = good
+                if out["others"][key]["verified"] is None:
+                    out["others"][key]["verified"] = bool(good) and not bad
                 if par:
                     out["others"][key]["cpu_baseline_all_cores"] = par
                 if bad:

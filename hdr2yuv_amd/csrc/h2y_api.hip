@@ -131,6 +131,7 @@ struct h2y_ctx {
     void *d_table1 = nullptr; /* binary32 first-tier records */
     void *d_table_ext = nullptr; /* pq_build_table_ext(): the binary64 table below 2^-24, read from global memory by pq_slow() */
     void *d_tfn[H2Y_TFN_COUNT] = {}; /* the other transfer functions' tables (tfn_build_table), built when first needed */
+    void *d_tfn_ext[H2Y_TFN_COUNT] = {}; /* and their full-range tables in global memory (tfn_build_ext; PQ10000_r's is d_table_ext) */
     float *d_lut16 = nullptr; /* PQ10000_r of every half in [0,2), built on the device at creation */
     /* The first tier is slow on pictures with many exactly-zero samples (black bars: every such tile is done twice).
      * The kernel counts the tiles it had to redo; when their share in a batch exceeds kT1DenseShare the next
@@ -157,7 +158,7 @@ struct h2y_ctx {
     double fir_flag_share = 0.0; /* share of the last k_fir_fused batch's pixels (in tiles of eight) the first tier could not settle */
     uint16_t *d_tmp = nullptr;
     size_t tmp_cap = 0;
-    uint16_t *d_up = nullptr; /* h2y_inverse_420(): the two upsampled chroma planes */
+    uint16_t *d_up = nullptr; /* (unused since k_inverse420 upsamples inside its blocks; freed for contexts that still hold one) */
     size_t up_cap = 0;
 
     /* staging for the host-buffer entry */
@@ -400,14 +401,15 @@ fused_variant pick_variant(const h2y_ctx *ctx, const h2y_desc *d, const pix_para
         bool ident = known != nullptr;
         for (int c = 0; c < 3 && ident; c++) ident = known->floor_[c] == 0 && known->ceil_[c] == 1;
         v.pipe = ident ? 1 : 2; /* 2 is always valid: (x - 0) / 1 == x exactly */
-        if (pp.convert_transfer == 2) v.pipe = 0; /* generic transfer pair: runtime kernel, careful tier */
+        if (pp.convert_transfer == 2) /* generic transfer pair: its two stages' tables, in the loop form where that exists */
+            v.pipe = (v.even_h && (pp.mode == H2Y_MODE_YCBCR || pp.mode == H2Y_MODE_YDZDX)) ? 7 /* H2Y_PIPE_TFN */ : 0;
         /* binary32 first tier where few pixels would fall through it (moderate bit depths) */
         if ((v.pipe == 1 || v.pipe == 2) && v.in_kind != H2Y_IN_U16 && (d->height & 1) == 0 && ctx->opt_t1 && t1_bounds(pp, sn)) {
             v.pipe += 3;
             v.t1_ok = true;
         }
         /* half input with the identity normalisation: the whole transfer is a 64 KB table */
-        if (ident && v.in_kind == H2Y_IN_F16 && v.even_h && (pp.mode == H2Y_MODE_YCBCR || pp.mode == H2Y_MODE_YDZDX)) v.pipe = 3;
+        if (pp.convert_transfer == 1 && ident && v.in_kind == H2Y_IN_F16 && v.even_h && (pp.mode == H2Y_MODE_YCBCR || pp.mode == H2Y_MODE_YDZDX)) v.pipe = 3;
     }
     return v;
 }
@@ -454,6 +456,15 @@ int ensure_tfn(h2y_ctx *ctx, int fn)
     ctx->d_tfn[fn] = t;
     HIP_TRY(ctx, hipMemcpy(t, A.data(), H2Y_PQ_NREC * 16, hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(t + H2Y_PQ_NREC * 16, B.data(), H2Y_PQ_NREC * 16, hipMemcpyHostToDevice));
+    if (fn == H2Y_TFN_PQ_R) ctx->d_tfn_ext[fn] = ctx->d_table_ext; /* the same function, the same layout */
+    else {
+        std::vector<pq_ext_rec> X(H2Y_PQX_NSEG);
+        (void)tfn_build_ext(fn, X.data());
+        void *x = nullptr;
+        HIP_TRY(ctx, hipMalloc(&x, H2Y_PQX_TABLE_BYTES));
+        ctx->d_tfn_ext[fn] = x;
+        HIP_TRY(ctx, hipMemcpy(x, X.data(), H2Y_PQX_TABLE_BYTES, hipMemcpyHostToDevice));
+    }
     return 0;
 }
 
@@ -843,7 +854,7 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         a.partial = ctx->b->d_partial;
         a.assumed = d_assumed;
         a.pp = pp;
-        if (pp.convert_transfer == 2 && !var.narrow && var.pipe == 0) {
+        if (pp.convert_transfer == 2 && !var.narrow && (var.pipe == 0 || var.pipe == 7)) {
             /* generic transfer pair through the table tier: source function, then destination function */
             static const int kSrcFn[4] = {H2Y_TFN_NONE, H2Y_TFN_PQ_F, H2Y_TFN_RHO_H, H2Y_TFN_G24};    /* by H2Y_TF_* class */
             static const int kDstFn[4] = {H2Y_TFN_NONE, H2Y_TFN_PQ_R, H2Y_TFN_RHO_R, H2Y_TFN_G24INV};
@@ -855,6 +866,8 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
             a.pp.dst_fn = df;
             a.table_src = sf ? ctx->d_tfn[sf] : nullptr;
             a.table_dst = df ? ctx->d_tfn[df] : nullptr;
+            a.pp.tf_ext[0] = sf ? ctx->d_tfn_ext[sf] : nullptr;
+            a.pp.tf_ext[1] = df ? ctx->d_tfn_ext[df] : nullptr;
         }
         a.tiles_magic = g.tiles > 1 ? (uint32_t)(0x100000000ull / g.tiles) : 0xFFFFFFFFu;
         const bool ev = time_it && ctx->b->n_ev < kMaxEvents;
@@ -862,7 +875,7 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
             HIP_TRY(ctx, hipEventRecord(ctx->b->ev[ctx->b->n_ev][0], ctx->stream));
             ctx->last_name = h2y_fused_name(var);
             static const char *const kIn[] = {"F32", "F16", "U16"}, *const kOut[] = {"420BOX", "444", "444TMP"};
-            static const char *const kPipe[] = {"RUNTIME", "PQ_IDENT", "PQ_NORM", "LUT16", "PQ_IDENT", "PQ_NORM", "NONE"};
+            static const char *const kPipe[] = {"RUNTIME", "PQ_IDENT", "PQ_NORM", "LUT16", "PQ_IDENT", "PQ_NORM", "NONE", "TFN"};
             const char *mode = var.mode == H2Y_MODE_YCBCR ? "YCBCR" : var.mode == H2Y_MODE_YDZDX ? "YDZDX" : var.mode == H2Y_MODE_IDENTITY ? "IDENTITY" : "YPQRS";
             char buf[192];
             snprintf(buf, sizeof buf, "%s<%s,%s,%s,%s%s>%s groups=%d xcd=%d", ctx->last_name, kIn[var.in_kind], kOut[var.out_kind], mode,
@@ -1203,6 +1216,8 @@ void h2y_ctx_destroy(h2y_ctx *ctx)
     }
     (void)hipFree(ctx->d_table);
     for (void *t : ctx->d_tfn) (void)hipFree(t);
+    for (int fn = 0; fn < H2Y_TFN_COUNT; fn++)
+        if (ctx->d_tfn_ext[fn] && ctx->d_tfn_ext[fn] != ctx->d_table_ext) (void)hipFree(ctx->d_tfn_ext[fn]);
     (void)hipFree(ctx->d_lut16);
     (void)hipFree(ctx->d_table1);
     (void)hipFree(ctx->d_table_ext);
@@ -1536,16 +1551,40 @@ int h2y_inverse_420(h2y_ctx *ctx, int width, int height, int in_bit_depth, int i
         return fail(ctx, H2Y_EINVAL, "4:2:0 inverse: width a multiple of 4 and height even, up to 32766"); /* the upsampled planes feed 8-byte loads */
     if (in_bit_depth < 8 || in_bit_depth > 16) return fail(ctx, H2Y_EINVAL, "bit depths must be 8..16");
     if (!d_in || !d_in[0] || !d_in[1] || !d_in[2]) return fail(ctx, H2Y_EINVAL, "null pointer arrays");
+    if (out_bit_depth < 8 || out_bit_depth > 16) return fail(ctx, H2Y_EINVAL, "bit depths must be 8..16");
+    if (in_matrix_coeffs == H2Y_MATRIX_GBR) return fail(ctx, H2Y_EUNSUPPORTED, "matrix_coeffs 0 (GBR) has no inverse in the reference (it exits)");
+    if (!d_out || !d_out[0] || !d_out[1] || !d_out[2]) return fail(ctx, H2Y_EINVAL, "null pointer arrays");
+    for (int c = 0; c < 3; c++)
+        if (((uintptr_t)d_in[c] & 3) || ((uintptr_t)d_out[c] & 3)) return fail(ctx, H2Y_EINVAL, "plane %d is not 4-byte aligned", c);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t npix = (size_t)width * height, plane_al = (npix * sizeof(uint16_t) + 255) & ~(size_t)255;
-    int rc = ensure(ctx, ctx->d_up, ctx->up_cap, 2 * plane_al);
-    if (rc) return rc;
-    uint16_t *cb = ctx->d_up, *cr = reinterpret_cast<uint16_t *>(reinterpret_cast<char *>(ctx->d_up) + plane_al);
-    /* yuv2tiff.cpp:92-93,142-154: minCV 0, maxCV 2^depth - 1 */
-    rc = upsample_launch(ctx, width, height, algorithm, 0u, (1u << in_bit_depth) - 1u, d_in[1], d_in[2], cb, cr);
-    if (rc) return rc;
-    const uint16_t *full[3] = {d_in[0], cb, cr};
-    return h2y_matrix_inverse(ctx, width, height, in_bit_depth, in_full_range, in_matrix_coeffs, out_bit_depth, full, d_out);
+    /* one pass: both chroma planes upsampled inside the blocks (yuv2tiff.cpp:92-93,142-154: minCV 0, maxCV 2^depth - 1), then
+     * matrix_inverse's pixel; the 4:4:4 chroma never reaches memory (k_inverse420, h2y_resample.hip) */
+    inv420_args a;
+    a.up.src0 = d_in[1]; a.up.src1 = d_in[2]; a.up.dst0 = a.up.dst1 = nullptr;
+    a.up.width = width; a.up.height = height;
+    a.up.algorithm = algorithm;
+    a.up.fmin = 0.0f; a.up.fmax = (float)((1u << in_bit_depth) - 1u);
+    const clip_limits ic = make_clip(in_bit_depth, in_full_range);
+    a.inv.in[0] = d_in[0]; a.inv.in[1] = a.inv.in[2] = nullptr;
+    for (int c = 0; c < 3; c++) a.inv.out[c] = d_out[c];
+    a.inv.npix = (uint32_t)width * (uint32_t)height;
+    a.inv.d709 = in_matrix_coeffs == H2Y_MATRIX_BT709;
+    a.inv.minVR = ic.minVR;
+    a.inv.maxVR = ic.maxVR;
+    a.inv.shift_right = in_bit_depth > out_bit_depth;
+    a.inv.shift = a.inv.shift_right ? in_bit_depth - out_bit_depth : out_bit_depth - in_bit_depth;
+    ctx->b->n_ev = 0;
+    HIP_TRY(ctx, hipEventRecord(ctx->b->ev[0][0], ctx->stream));
+    HIP_TRY(ctx, h2y_launch_inverse420(ctx->stream, a));
+    HIP_TRY(ctx, hipEventRecord(ctx->b->ev[0][1], ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->b->ev[0][0], ctx->b->ev[0][1]));
+    ctx->last_ms = ms;
+    ctx->last_launches = 1;
+    ctx->last_name = "k_inverse420";
+    ctx->last_variant = algorithm ? "k_inverse420<FIR>" : "k_inverse420<REPLICATE>";
+    return H2Y_OK;
 }
 
 int h2y_inverse_frame(h2y_ctx *ctx, int width, int height, int in_chroma_format_idc, int in_bit_depth, int in_full_range,

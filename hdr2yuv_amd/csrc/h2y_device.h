@@ -255,12 +255,12 @@ __device__ __attribute__((noinline)) ycc pixel_careful(const pix_params *spp /* 
  * frame: 2.39 ms against 1.76).  `slow` in: the LDS tier's verdict; out: still unsettled (ambiguous rounding, subnormal,
  * negative, NaN, >= 2: the careful tier as before). */
 typedef const __attribute__((address_space(4))) uint32_t *h2y_const_u32;
-__device__ __forceinline__ float pq_ext_inline(float x, float v, bool &slow, const void *ext)
+__device__ __forceinline__ float pq_ext_inline(float x, float v, bool &slow, const void *ext, uint32_t lo_bits = (uint32_t)(127 + H2Y_PQ_EMIN) << 23)
 {
     const uint32_t xb = f2bits(x);
-    /* candidates: flagged, and 2^-126 <= x < 2^-24 (in the LDS table's own domain a flag means an ambiguous rounding,
-     * which the same polynomial would only repeat) */
-    const bool cand = slow && (xb - 0x00800000u) < (((uint32_t)(127 + H2Y_PQ_EMIN) << 23) - 0x00800000u);
+    /* candidates: flagged, and 2^-126 <= x < the LDS table's lowest float, 2^-24 for PQ10000_r (in the LDS table's own
+     * domain a flag means an ambiguous rounding, which the same polynomial would only repeat) */
+    const bool cand = slow && (xb - 0x00800000u) < (lo_bits - 0x00800000u);
     uint64_t m = __builtin_amdgcn_ballot_w64(cand);
     if (__builtin_expect(m != 0 && ext != nullptr, 0)) {
         const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
@@ -291,10 +291,10 @@ __device__ __forceinline__ float pq_ext_inline(float x, float v, bool &slow, con
 /* The same for code that has no picture loads in flight (k_fused_t1's redo passes, k_fused): every candidate lane reads ITS record
  * with two 16-byte vector loads -- one latency for the wave however many lanes hold such a sample (a redo pass over a dark
  * picture has several per pixel position, which the scalar form would take one after the other). */
-__device__ __forceinline__ float pq_ext_gather(float x, float v, bool &slow, const void *ext)
+__device__ __forceinline__ float pq_ext_gather(float x, float v, bool &slow, const void *ext, uint32_t lo_bits = (uint32_t)(127 + H2Y_PQ_EMIN) << 23)
 {
     const uint32_t xb = f2bits(x);
-    const bool cand = slow && (xb - 0x00800000u) < (((uint32_t)(127 + H2Y_PQ_EMIN) << 23) - 0x00800000u);
+    const bool cand = slow && (xb - 0x00800000u) < (lo_bits - 0x00800000u);
     if (__builtin_expect(__builtin_amdgcn_ballot_w64(cand) != 0 && ext != nullptr, 0)) {
         const uint32_t idx = cand ? (xb >> H2Y_PQ_LOW_BITS) - H2Y_PQX_SEG_BASE : 0u;
         const pq_ext_rec *X = reinterpret_cast<const pq_ext_rec *>(ext);
@@ -317,6 +317,7 @@ static __device__ __attribute__((noinline)) float tf_from_linear_careful(int cls
 #define H2Y_PIPE_PQ_IDENT 1 /* LINEAR -> PQ, floor 0 / ceiling 1: no normalisation arithmetic */
 #define H2Y_PIPE_PQ_NORM 2  /* LINEAR -> PQ with (x - offset) / range */
 #define H2Y_PIPE_NONE 6     /* equal transfers: the samples go to the matrix as they are (k_fused2 only) */
+#define H2Y_PIPE_TFN 7      /* any other transfer pair through its two stages' tables (pp.src_fn / pp.dst_fn), loop form (k_fused2 only) */
 
 /* normalisation of one sample, convert.cpp:1017-1019: binary32 subtract, IEEE divide */
 template <int PIPE> __device__ __forceinline__ float norm1(const pix_params &pp, int c, float v)
@@ -352,14 +353,21 @@ __device__ __forceinline__ bool pixel_fast(const pix_params &pp, const pq_recA *
                 bool s1;
                 const float x0 = x;
                 if (pp.src_fn == H2Y_TFN_RHO_H) x = (powf25(x) - 1.0f) * 0.0625f; /* RHO_GAMMA_f's inner powf, then (P - 1) / 16: both exact */
+                const float xin = x;
                 x = tfn_fast(x, t_src, tfn_cut_of(pp.src_fn), tfn_zero_bits(pp.src_fn), tfn_one_bits(pp.src_fn), &s1);
-                if (__builtin_expect(s1, 0)) x = tf_to_linear_careful(pp.src_tf, x0); /* this sample alone, not its pixel */
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(s1) != 0, 0)) {
+                    x = pq_ext_gather(xin, x, s1, pp.tf_ext[0], tfn_lo_bits(pp.src_fn)); /* below the LDS table: the function's full-range table */
+                    if (s1) x = tf_to_linear_careful(pp.src_tf, x0); /* this sample alone, not its pixel */
+                }
             }
             if (pp.dst_fn) {
                 bool s2;
                 const float x1 = x;
                 x = tfn_fast(x, t_dst, tfn_cut_of(pp.dst_fn), tfn_zero_bits(pp.dst_fn), tfn_one_bits(pp.dst_fn), &s2);
-                if (__builtin_expect(s2, 0)) x = tf_from_linear_careful(pp.dst_tf, x1);
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(s2) != 0, 0)) {
+                    x = pq_ext_gather(x1, x, s2, pp.tf_ext[1], tfn_lo_bits(pp.dst_fn));
+                    if (s2) x = tf_from_linear_careful(pp.dst_tf, x1);
+                }
             }
             unsure |= !(x == x); /* a NaN (negative sample through a power, ...) takes its pixel to the careful matrix: the reference's x86 conversions */
             v[c] = x;
@@ -467,6 +475,44 @@ template <int THREADS> __device__ __forceinline__ void stage_lut16_scaled(const 
         ly[i] = f32x4{pix_scale(q.x, pp.mulY, pp.addY), pix_scale(q.y, pp.mulY, pp.addY), pix_scale(q.z, pp.mulY, pp.addY), pix_scale(q.w, pp.mulY, pp.addY)};
         lc[i] = f32x4{pix_scale(q.x, pp.mulC, pp.addC), pix_scale(q.y, pp.mulC, pp.addC), pix_scale(q.z, pp.mulC, pp.addC), pix_scale(q.w, pp.mulC, pp.addC)};
     }
+}
+
+/* ---- matrix_inverse (convert.cpp:1320-1867), one pixel: see k_inverse (h2y_kernels.hip) for the behaviour kept ----
+ * BT.709 green: the reference divides by 0.7152 in binary64.  Here: one fused multiply-add with the reciprocal, and the IEEE
+ * division only when the result's rounding to float could differ (its low 29 bits within 4096 ulp(double) of the tie:
+ * the reciprocal form is off by an ulp or two; 1.5e-5 of the pixels). */
+__device__ __forceinline__ void inverse_pixel(const inverse_args &a, uint32_t y, uint32_t cb, uint32_t cr, uint32_t &G, uint32_t &B, uint32_t &R)
+{
+    float Yav = (float)y;
+    const float Cb = (float)cb, Cr = (float)cr;
+    float Rp, Bp;
+    if (!a.d709) {
+        Rp = (float)((2.0 * (double)Cr - 4095.0) + (double)Yav);
+        Bp = (float)((2.0 * (double)Cb - 4095.0) + (double)Yav);
+    } else {
+        float t = (float)(((double)Cb - 2047.5) * 1.8556 + (double)Yav);
+        if (t > 4095.0f) t = 4095.0f;
+        Bp = t;
+        t = (float)(((double)Cr - 2047.5) * 1.5748 + (double)Yav);
+        if (t > 4095.0f) t = 4095.0f;
+        Rp = t;
+        const double num = ((double)Yav - 0.07222 * (double)Bp) - 0.2126 * (double)Rp;
+        double q = __builtin_fma(num, 1.0 / 0.7152, 0.5);
+        if (__builtin_expect(pq_ambiguous(q), 0)) q = num / 0.7152 + 0.5;
+        t = (float)q;
+        if (t > 4095.0f) t = 4095.0f;
+        Yav = t;
+    }
+    int g = sat_i32_f32(Yav), b = sat_i32_f32(Bp), r = sat_i32_f32(Rp);
+    /* negative -> 0, then the clamp to [minVR, maxVR] (minVR >= 0): one clamp does both */
+    g = min(max(g, (int)a.minVR), (int)a.maxVR);
+    b = min(max(b, (int)a.minVR), (int)a.maxVR);
+    r = min(max(r, (int)a.minVR), (int)a.maxVR);
+    if (a.shift_right) { g >>= a.shift; b >>= a.shift; r >>= a.shift; }
+    else { g <<= a.shift; b <<= a.shift; r <<= a.shift; }
+    G = (uint32_t)g & 0xFFFFu; /* stored into an unsigned short */
+    B = (uint32_t)b & 0xFFFFu;
+    R = (uint32_t)r & 0xFFFFu;
 }
 
 #endif /* H2Y_DEVICE_H */

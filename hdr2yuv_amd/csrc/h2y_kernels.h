@@ -170,6 +170,11 @@ struct up_args { /* k_up444: one or two chroma planes, (width/2 x height/2) -> (
     float fmin, fmax;            /* (float) of minCV / maxCV, convert.cpp:1932-1934 */
 };
 
+struct inv420_args { /* k_inverse420: Subsample420to444 of both chroma planes and matrix_inverse in one pass */
+    up_args up;       /* src0/src1 = the 4:2:0 Cb/Dz and Cr/Dx planes; dst0/dst1 unused; width, height, algorithm, fmin, fmax */
+    inverse_args inv; /* in[0] = the luma plane (in[1], in[2] unused), out[3] = G, B, R */
+};
+
 /* k_fir_fused: lanes of a wave that own chroma columns (the others, half on either side, only feed the horizontal taps):
  * a strip is 4 x this many picture columns */
 #ifndef H2Y_FF_OWN_LANES
@@ -194,6 +199,7 @@ hipError_t h2y_launch_inverse(int grid, hipStream_t st, const inverse_args &a);
 static inline uint32_t h2y_firf_vblock(uint32_t b) { return (b & ~6u) | ((b & 2u) << 1) | ((b & 4u) >> 1); }
 hipError_t h2y_launch_fir_fused(int in_kind, int mode, bool ident, bool lut16, int grid, hipStream_t st, const firf_args &a);
 hipError_t h2y_launch_up444(hipStream_t st, const up_args &a);
+hipError_t h2y_launch_inverse420(hipStream_t st, const inv420_args &a);
 hipError_t h2y_launch_box420(hipStream_t st, const uint16_t *src, uint16_t *dst, int W, int H);
 
 #endif

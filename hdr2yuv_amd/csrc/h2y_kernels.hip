@@ -451,18 +451,97 @@ __device__ __forceinline__ float pq_sample_rec(const pix_params &pp, int c, floa
     any_slow |= slow2; /* through pq_slow(): the value may be NaN */
     return pix_scale(v, c == 0 ? pp.mulY : pp.mulC, c == 0 ? pp.addY : pp.addC);
 }
+/* H2Y_PIPE_TFN: the three samples of a pixel through ONE stage of a generic transfer pair (convert.cpp:1024-1109: source
+ * function -> linear light, a float as in the reference -> destination function), the stage's table in LDS (tfn_fast's
+ * arithmetic, with the six records of the pixel on their way before the first is used); what the table does not reach through
+ * the stage's full-range table in global memory by scalar loads (pq_ext_inline: no wait for the prefetch); what is left
+ * (ambiguous roundings, subnormals, NaNs) through the careful tier, sample by sample. */
+/* what tfn_index() / tfn_fast() derive from the function's number, worked out once per kernel (scalar registers) */
+struct tfn_consts {
+    uint32_t lo_base, hi_base;   /* first float (bits) of the table's low part and of its finer high part (0x80000000: none) */
+    uint32_t lo_shift, hi_shift; /* 23 - seg_bits of either part */
+    uint32_t nseg_lo;            /* segments of the low part */
+    uint32_t zero_bits, one_bits, lo_bits;
+    uint32_t rho_h;              /* the source stage starts with RHO_GAMMA_f's inner powf */
+    __device__ __forceinline__ void set(int fn)
+    {
+        const tfn_cut c = tfn_cut_of(fn);
+        lo_base = (uint32_t)(127 + c.emin) << 23;
+        hi_base = c.hi_emin < 1 ? (uint32_t)(127 + c.hi_emin) << 23 : 0x80000000u; /* (none: no non-negative float reaches it) */
+        lo_shift = 23u - (uint32_t)c.seg_bits;
+        hi_shift = 23u - (uint32_t)c.hi_seg_bits;
+        nseg_lo = (uint32_t)tfn_nseg_lo(c);
+        zero_bits = tfn_zero_bits(fn);
+        one_bits = tfn_one_bits(fn);
+        lo_bits = tfn_lo_bits(fn);
+        rho_h = fn == H2Y_TFN_RHO_H;
+    }
+};
+template <bool SRC>
+__device__ __forceinline__ void tfn_stage3(const pix_params &pp, const tfn_consts &k, const pq_recA *tab, const void *ext, float (&x)[3])
+{
+    float x0[3];
+    uint32_t bits[3], idx[3], low_bits[3];
+    pq_recA ra[3];
+    pq_recB rb[3];
+    if (SRC && k.rho_h) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            x0[c] = x[c];
+            x[c] = (powf25(x[c]) - 1.0f) * 0.0625f; /* RHO_GAMMA_f's inner powf, then (P - 1) / 16: both exact */
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; c++) x0[c] = x[c];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        bits[c] = f2bits(x[c]);
+        /* tfn_index(): everything outside the table (0, tiny, >= 2, negative, NaN) wraps above it and lands on the sentinel */
+        const bool hi = bits[c] >= k.hi_base && (int32_t)bits[c] >= 0;
+        const uint32_t i_lo = (bits[c] - k.lo_base) >> k.lo_shift, i_hi = k.nseg_lo + ((bits[c] - k.hi_base) >> k.hi_shift);
+        idx[c] = umin32(hi ? i_hi : i_lo, (uint32_t)H2Y_PQ_NSEG);
+        low_bits[c] = hi ? k.hi_shift : k.lo_shift;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        ra[c] = tab[idx[c]];
+        rb[c] = reinterpret_cast<const pq_recB *>(tab + H2Y_PQ_NREC)[idx[c]];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const double v = tfn_poly(bits[c], 23 - (int)low_bits[c], ra[c], rb[c]);
+        const bool zero = bits[c] == 0u, one = k.one_bits != 0u && bits[c] == 0x3F800000u;
+        bool slow = pq_ambiguous(v) & !(zero | one);
+        float r = zero ? bits2f(k.zero_bits) : one ? bits2f(k.one_bits) : (float)v;
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(slow) != 0, 0)) {
+            r = pq_ext_inline(x[c], r, slow, ext, k.lo_bits);
+            if (slow) r = SRC ? tf_to_linear_careful(pp.src_tf, x0[c]) : tf_from_linear_careful(pp.dst_tf, x0[c]);
+        }
+        x[c] = r;
+    }
+}
 template <int IN_KIND, int OUT_KIND, int MODE, int PIPE>
 __global__ __launch_bounds__(H2Y_LOOP_THREADS) void k_fused2(fused_args a)
 {
-    __shared__ pq_recA s_tab[PIPE == H2Y_PIPE_NONE ? 1 : 2 * H2Y_PQ_NREC]; /* A records, then B records */
+    __shared__ pq_recA s_tab[PIPE == H2Y_PIPE_NONE ? 1 : (PIPE == H2Y_PIPE_TFN ? 4 : 2) * H2Y_PQ_NREC]; /* A records, then B records (TFN: of the source stage, then of the destination stage) */
     const pq_recA *sA = s_tab;
     const pq_recB *sB = reinterpret_cast<const pq_recB *>(s_tab + (PIPE == H2Y_PIPE_NONE ? 0 : H2Y_PQ_NREC));
     __shared__ uint32_t s_claim[H2Y_CLAIM_FRAMES], s_scratch[WAVE];
     __shared__ const void *s_ext; /* a.pp.pq_ext, for the rare pq_slow() */
-    if (PIPE != H2Y_PIPE_NONE) stage_table<H2Y_LOOP_THREADS>(a.table, s_tab);
+    if (PIPE == H2Y_PIPE_TFN) {
+        if (a.table_src) stage_table<H2Y_LOOP_THREADS>(a.table_src, s_tab);
+        if (a.table_dst) stage_table<H2Y_LOOP_THREADS>(a.table_dst, s_tab + (PIPE == H2Y_PIPE_TFN ? 2 * H2Y_PQ_NREC : 0));
+    } else if (PIPE != H2Y_PIPE_NONE) stage_table<H2Y_LOOP_THREADS>(a.table, s_tab);
     if (threadIdx.x < H2Y_CLAIM_FRAMES) s_claim[threadIdx.x] = 0u;
     if (threadIdx.x == 0) s_ext = a.pp.pq_ext;
     const pix_params pp = with_assumed(a.pp, a.assumed);
+    tfn_consts k_src, k_dst; /* H2Y_PIPE_TFN: the two stages' table geometry */
+    if (PIPE == H2Y_PIPE_TFN) {
+        k_src.set(pp.src_fn > 0 ? pp.src_fn : H2Y_TFN_PQ_R);
+        k_dst.set(pp.dst_fn > 0 ? pp.dst_fn : H2Y_TFN_PQ_R);
+    }
     __syncthreads();
 
     block_clock_start(a);
@@ -526,7 +605,15 @@ __global__ __launch_bounds__(H2Y_LOOP_THREADS) void k_fused2(fused_args a)
                     bool odd = false; /* a sample went through pq_slow(): it may be NaN (negative input, 0/0 normalisation) */
                     float g, b, r;
                     if (PIPE == H2Y_PIPE_NONE) { g = gv[col]; b = bv[col]; r = rv[col]; }
-                    else {
+                    else if (PIPE == H2Y_PIPE_TFN) {
+                        float x[3] = {norm1<H2Y_PIPE_RUNTIME>(pp, 0, gv[col]), norm1<H2Y_PIPE_RUNTIME>(pp, 1, bv[col]), norm1<H2Y_PIPE_RUNTIME>(pp, 2, rv[col])};
+                        if (pp.src_fn > 0) tfn_stage3<true>(pp, k_src, s_tab, pp.tf_ext[0], x);
+                        if (pp.dst_fn > 0) tfn_stage3<false>(pp, k_dst, s_tab + 2 * H2Y_PQ_NREC, pp.tf_ext[1], x);
+                        odd = !(x[0] == x[0]) | !(x[1] == x[1]) | !(x[2] == x[2]); /* a NaN (negative sample through a power, ...): the careful matrix */
+                        g = pix_scale(x[0], pp.mulY, pp.addY);
+                        b = pix_scale(x[1], pp.mulC, pp.addC);
+                        r = pix_scale(x[2], pp.mulC, pp.addC);
+                    } else {
                         /* the six table records of a pixel on their way before the first is used */
                         const float xg = norm1<PIPE>(pp, 0, gv[col]), xb = norm1<PIPE>(pp, 1, bv[col]), xr = norm1<PIPE>(pp, 2, rv[col]);
                         const pq_rec cg = pq_fetch(xg, sA, sB), cb = pq_fetch(xb, sA, sB), cr = pq_fetch(xr, sA, sB);
@@ -1522,36 +1609,6 @@ __global__ __launch_bounds__(256) void k_fir420(fir_args a)
  * (the test at convert.cpp:1391 compares matrix_coeffs with booleans), everything else Y'DzDx; the
  * video-range clamp always runs, with the input picture's limits.
  */
-__device__ __forceinline__ void inverse_pixel(const inverse_args &a, uint32_t y, uint32_t cb, uint32_t cr, uint32_t &G, uint32_t &B, uint32_t &R)
-{
-    float Yav = (float)y;
-    const float Cb = (float)cb, Cr = (float)cr;
-    float Rp, Bp;
-    if (!a.d709) {
-        Rp = (float)((2.0 * (double)Cr - 4095.0) + (double)Yav);
-        Bp = (float)((2.0 * (double)Cb - 4095.0) + (double)Yav);
-    } else {
-        float t = (float)(((double)Cb - 2047.5) * 1.8556 + (double)Yav);
-        if (t > 4095.0f) t = 4095.0f;
-        Bp = t;
-        t = (float)(((double)Cr - 2047.5) * 1.5748 + (double)Yav);
-        if (t > 4095.0f) t = 4095.0f;
-        Rp = t;
-        t = (float)((((double)Yav - 0.07222 * (double)Bp) - 0.2126 * (double)Rp) / 0.7152 + 0.5);
-        if (t > 4095.0f) t = 4095.0f;
-        Yav = t;
-    }
-    int g = sat_i32_f32(Yav), b = sat_i32_f32(Bp), r = sat_i32_f32(Rp);
-    /* negative -> 0, then the clamp to [minVR, maxVR] (minVR >= 0): one clamp does both */
-    g = min(max(g, (int)a.minVR), (int)a.maxVR);
-    b = min(max(b, (int)a.minVR), (int)a.maxVR);
-    r = min(max(r, (int)a.minVR), (int)a.maxVR);
-    if (a.shift_right) { g >>= a.shift; b >>= a.shift; r >>= a.shift; }
-    else { g <<= a.shift; b <<= a.shift; r <<= a.shift; }
-    G = (uint32_t)g & 0xFFFFu; /* stored into an unsigned short */
-    B = (uint32_t)b & 0xFFFFu;
-    R = (uint32_t)r & 0xFFFFu;
-}
 __global__ __launch_bounds__(256) void k_inverse(inverse_args a)
 {
     const uint32_t n4 = a.npix >> 2;
@@ -1588,6 +1645,7 @@ template <int IN_KIND, int OUT_KIND, int MODE> static fused_fn pick_pipe(int pip
     case H2Y_PIPE_PQ_IDENT: return even_h ? k_fused2<IN_KIND, OUT_KIND, MODE, H2Y_PIPE_PQ_IDENT> : k_fused<IN_KIND, OUT_KIND, MODE, H2Y_PIPE_PQ_IDENT>;
     case H2Y_PIPE_PQ_NORM: return even_h ? k_fused2<IN_KIND, OUT_KIND, MODE, H2Y_PIPE_PQ_NORM> : k_fused<IN_KIND, OUT_KIND, MODE, H2Y_PIPE_PQ_NORM>;
     case H2Y_PIPE_NONE: return k_fused2<IN_KIND, OUT_KIND, MODE, H2Y_PIPE_NONE>;
+    case H2Y_PIPE_TFN: return k_fused2<IN_KIND, OUT_KIND, MODE, H2Y_PIPE_TFN>;
     default: return k_fused<IN_KIND, OUT_KIND, MODE, H2Y_PIPE_RUNTIME>;
     }
 }
@@ -1632,6 +1690,7 @@ const char *h2y_fused_name(const fused_variant &v)
     if (v.narrow) return "k_fused_narrow";
     if (v.pipe == 3) return "k_fused_lut16";
     if (v.pipe == 4 || v.pipe == 5) return "k_fused_t1";
+    if (v.pipe == H2Y_PIPE_TFN) return "k_fused2";
     return ((v.pipe == 1 || v.pipe == 2 || v.pipe == H2Y_PIPE_NONE) && v.even_h && (v.mode == H2Y_MODE_YCBCR || v.mode == H2Y_MODE_YDZDX)) ? "k_fused2" : "k_fused";
 }
 bool h2y_fused_grouped(const fused_variant &v)

@@ -755,10 +755,9 @@ H2Y_FN uint32_t tfn_segment_bits(int i, tfn_cut c, int *seg_bits)
 
 /* Generic form of pq_build_table() with the per-segment check described above.  Returns how many segments of the
  * table's domain ended up on the sentinel.  Records beyond the cut's last segment are sentinels too. */
-inline int tfn_build_table(int fn, pq_recA *A, pq_recB *B)
+inline int tfn_build_records(int fn, tfn_cut cut, int last_rec /* records 0 .. last_rec are written; beyond the cut: sentinels */, pq_recA *A, pq_recB *B)
 {
     const double un[5] = {-0.9510565162951535, -0.5877852522924731, 0.0, 0.5877852522924731, 0.9510565162951535};
-    const tfn_cut cut = tfn_cut_of(fn);
     const int nseg = tfn_nseg(cut);
     std::vector<unsigned char> bad(nseg, 0); /* 1: not accurate enough or not defined here; 2: a kink (takes its neighbours along) */
     for (int i = 0; i < nseg; i++) {
@@ -816,7 +815,7 @@ inline int tfn_build_table(int fn, pq_recA *A, pq_recB *B)
         bad[i] = kink ? 2 : (ok ? 0 : 1);
     }
     int nbad = 0;
-    for (int i = 0; i <= H2Y_PQ_NSEG; i++) {
+    for (int i = 0; i <= last_rec; i++) {
         bool b = i >= nseg || bad[i]; /* a kink takes its two neighbours on either side with it */
         for (int k = -2; k <= 2 && !b; k++) b = i + k >= 0 && i + k < nseg && bad[i + k] == 2;
         if (b) {
@@ -829,6 +828,26 @@ inline int tfn_build_table(int fn, pq_recA *A, pq_recB *B)
     }
     return nbad;
 }
+inline int tfn_build_table(int fn, pq_recA *A, pq_recB *B) { return tfn_build_records(fn, tfn_cut_of(fn), H2Y_PQ_NSEG, A, B); }
+/* The same function over EVERY normal float below 2 (64 segments per binade from 2^-126: the layout and size of
+ * pq_build_table_ext), for global memory: what a stage's LDS table does not reach -- linear light below 2^-24 coming out of
+ * a source function, PQ code values below 2^-12 -- is answered from here (tfn_ext_inline / tfn_ext_gather, h2y_device.h)
+ * before the double-double careful tier (30 us of a wave's time per sample).  Segments the polynomial cannot be trusted on
+ * carry the sentinel as in the LDS tables.  H2Y_TFN_PQ_R's is pq_build_table_ext() itself. */
+inline int tfn_build_ext(int fn, pq_ext_rec *X)
+{
+    const tfn_cut cut = {H2Y_PQ_SEG_BITS, H2Y_PQX_EMIN, H2Y_PQ_SEG_BITS, 1};
+    std::vector<pq_recA> A(H2Y_PQX_NSEG);
+    std::vector<pq_recB> B(H2Y_PQX_NSEG);
+    const int nbad = tfn_build_records(fn, cut, H2Y_PQX_NSEG - 1, A.data(), B.data());
+    for (int i = 0; i < H2Y_PQX_NSEG; i++) {
+        X[i].a = A[i];
+        X[i].b = B[i];
+    }
+    return nbad;
+}
+/* lowest float (bits) of a function's LDS table: samples below it are the ones its full-range table is asked for */
+H2Y_FN uint32_t tfn_lo_bits(int fn) { return (uint32_t)(127 + tfn_cut_of(fn).emin) << 23; }
 /* one stage through its table (A, then B = A + H2Y_PQ_NREC records): pq_fast() with the function's own cut and value
  * at +0.0 */
 H2Y_FN float tfn_fast(float x, const pq_recA *__restrict__ A, tfn_cut cut, uint32_t zero_bits, uint32_t one_bits, bool *slow)
@@ -1032,7 +1051,8 @@ struct pix_params {
     /* the same limits on the UNSHIFTED value (pix_limits_finish): lo << s and (hi << s) | (2^s - 1),
      * and for the 2x2 box sum of four chroma values (s + 2) */
     uint32_t ylo_s, yhi_s, clo_s, chi_s, clo_b, chi_b;
-    const void *pq_ext;        /* pq_build_table_ext() in device memory (NULL: none): read by the careful paths only */
+    const void *pq_ext;        /* pq_build_table_ext() in device memory (NULL: none): samples below the LDS tables */
+    const void *tf_ext[2];     /* convert_transfer == 2: tfn_build_ext() of the source and destination stage (NULL: none) */
 };
 inline void pix_limits_finish(pix_params *pp)
 {

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""oracle/cpu_bench.py W H RESAMPLER DST_DEPTH DST_MATRIX FRAME [FRAME ...] -- TEST INFRASTRUCTURE ONLY.
+"""oracle/cpu_bench.py [--src-transfer T --dst-transfer T] W H RESAMPLER DST_DEPTH DST_MATRIX FRAME [FRAME ...] -- TEST INFRASTRUCTURE ONLY.
 One single-threaded process of the CPU reference path (oracle/_ref when it travelled with the repo, else
 the C restatement) converting the synthetic frames with the given indices (SURVEY 8c generator, seed
 12345 + index); prints "<kind> <seconds>" and one "md5 <index> <md5 of the .yuv frame>" line per frame.
@@ -16,13 +16,18 @@ from oracle import binding as ob
 
 
 def main():
-    w, h, res, depth, mat = (int(x) for x in sys.argv[1:6])
-    frames = [int(x) for x in sys.argv[6:]]
+    argv = sys.argv[1:]
+    tf = {}
+    while argv and argv[0] in ("--src-transfer", "--dst-transfer"):
+        tf["src_transfer" if argv[0] == "--src-transfer" else "dst_transfer"] = int(argv[1])
+        argv = argv[2:]
+    w, h, res, depth, mat = (int(x) for x in argv[:5])
+    frames = [int(x) for x in argv[5:]]
     try:
         impl, kind = ob.Ref(build=False), "reference"
     except Exception:
         impl, kind = ob.Oracle(), "port"
-    d = ob.make_desc(width=w, height=h, dst_depth=depth, dst_matrix=mat, resampler=res)
+    d = ob.make_desc(width=w, height=h, dst_depth=depth, dst_matrix=mat, resampler=res, **tf)
     inputs = [synth_frame(w, h, k) for k in frames]
     outs = []
     t0 = time.perf_counter()

@@ -463,6 +463,54 @@ def test_other_transfer_pairs(ctx, oracle, src, dst):
         assert np.array_equal(got, want), (mat, np.count_nonzero(got != want))
 
 
+@pytest.mark.parametrize("src,dst", [(16, 8), (8, 1), (1, 16), (16, 1), (18, 16), (8, 18), (16, 18)])
+@pytest.mark.parametrize("sample", ["f32", "f16", "u16"])
+def test_transfer_pairs_loop_kernel_dark_batches(oracle, src, dst, sample):
+    """The generic pairs in the loop-form kernel (k_fused2<...,TFN>: both stages' tables in LDS, what they do not reach
+    from the stages' full-range tables in global memory, by scalar loads) on batches -- second round on the statistics
+    hint -- of DARK frames: uniform noise cubed, so that 0.4 % of the samples fall below a 2^-24 table floor and 6 % below
+    PQ10000_f's 2^-12, plus zeros and a few negatives and values above one.  Half input must not take the LINEAR -> PQ
+    table kernel (k_fused_lut16) for another pair, whatever the statistics."""
+    import torch
+
+    rng = np.random.default_rng(700 + src * 31 + dst)
+    w, hh, n = 256, 64, 4
+    host = []
+    for k in range(n):
+        planes = [(rng.random(w * hh, dtype=np.float32) ** 3).astype(np.float32) for _ in range(3)]
+        for p in planes:
+            p[0], p[1] = 0.0, 1.0
+            idx = rng.integers(2, p.size, 6)
+            p[idx[:3]] = 0.0
+            if sample == "f32":
+                p[idx[3]] = np.float32(-0.01)
+                p[idx[4]] = np.float32(1.25)
+        if sample == "f16":
+            planes = [p.astype(np.float16).view(np.uint16) for p in planes]
+        elif sample == "u16":
+            planes = [np.minimum(p * 4095.0, 4095.0).astype(np.uint16) for p in planes]
+        host.append(planes)
+    kind = {"f32": h.SAMPLE_F32, "f16": h.SAMPLE_F16, "u16": h.SAMPLE_U16}[sample]
+    for (mat, depth, chroma, res) in ((h.MATRIX_BT2020NC, 12, h.CHROMA_420, 0), (h.MATRIX_BT709, 10, h.CHROMA_420, 1), (h.MATRIX_YDZDX, 12, h.CHROMA_444, 0)):
+        d = h.make_desc(w, hh, sample=kind, src_depth=12 if sample == "u16" else 32, dst_depth=depth, src_transfer=src, dst_transfer=dst,
+                        dst_matrix=mat, chroma=chroma, resampler=res)
+        od = _to_oracle_desc(d)
+        want = [oracle.convert_frame(od, fr) for fr in host]
+        c = h.Context(0)
+        try:
+            dev_in = [[torch.from_numpy(np.ascontiguousarray(p).view(np.int16) if p.dtype == np.uint16 else p).cuda() for p in fr] for fr in host]
+            for rnd in range(2):
+                dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda") for _ in host]
+                torch.cuda.synchronize()
+                c.convert_batch(d, dev_in, dev_out)
+                assert c.last_kernel_name() == "k_fused2" and ",TFN" in c.last_kernel_variant(), c.last_kernel_variant()
+                for f in range(n):
+                    got = dev_out[f].cpu().numpy().view(np.uint16)
+                    assert np.array_equal(got, want[f]), (sample, src, dst, mat, rnd, f, int(np.count_nonzero(got != want[f])))
+        finally:
+            c.close()
+
+
 def test_rho_gamma_source_out_of_range_samples(ctx, oracle):
     """RHO_GAMMA_f on samples outside [0, 1]: negative V gives (25^V - 1) / 24 < 0 and pow(negative, 2.4) = NaN, large V
     overflows powf to infinity: the reference's conversions of those, byte for byte."""

@@ -60,6 +60,8 @@ const double kT1DenseShare = 0.08; /* T1 costs ~1.6x more per redone tile, k_fus
  * against k_fused2's 1.6), staying on the binary64 tier too long is cheap (2-10 % slower than the first tier on content that
  * suits it): probe rarely -- after 32 batches, then 64, ... 1024. */
 const double kFirSyncMaxFlagged = 0.004; /* k_fir_fused: tiles-of-eight share of unsettled pixels above which its waves are left out of step */
+const int kTailMinFrames = 8; /* frames per group from which its last one is drawn dynamically (h2y_walk.h): the plain loop that takes it is
+                                 slower than the prefetching one, and a frame is 1/8 of the group's work at most */
 const int kT1SkipBatches = 32;
 const int kT1SkipBatchesMax = 1024;
 const int kFirSubBatch = 32; /* frames per fused launch on the FIR path: every launch pays its table staging and its last redo pass */
@@ -90,6 +92,10 @@ struct batch_state {
      * block reads two words of it, once) -- no copy command between two launches.  Two, because the launches of one batch may
      * need different tables (the last one, when it holds fewer frames) while the earlier ones have not run yet. */
     uint32_t *h_ranges = nullptr, *hd_ranges = nullptr; /* host and device address of the same 2 x kRangeWords words */
+    uint32_t *d_tail = nullptr; /* the dynamic last frame's counters: [16 groups][H2Y_TAIL_WORDS]: counters and exhausted bits, zero between launches (k_stats_final) */
+    float *h_btime = nullptr, *hd_btime = nullptr; /* every block's run time of a timed launch (pinned, written by k_stats_final) */
+    int bal_grid = 0, bal_groups = 0;              /* the launch those times (and bal_bwork) belong to; 0: none */
+    std::vector<double> bal_bwork;                 /* relative work each block of the grid had in that launch */
     std::vector<uint32_t> range_slot[2];      /* what the two tables hold */
     bool slot_busy[2] = {false, false};       /* a launch of the batch being queued reads it */
     /* k_fir_fused: the rows of every unit (frame, segment, strip), cut by XCD speed */
@@ -141,6 +147,8 @@ struct h2y_ctx {
      * of each XCD; the shares of the next launch follow the speeds seen (balance_update()). */
     bool bal_have = false;
     double bal_speed[8] = {1, 1, 1, 1, 1, 1, 1, 1};
+    std::vector<double> bal_bspeed; /* per block of the grid (round 3): what is left between blocks once their XCDs are level */
+    int bal_bgrid = 0, bal_bgroups = 0; /* the grid shape bal_bspeed is for */
     bool ffb_have = false;                    /* k_fir_fused has its own speeds: it is vector-issue bound, the XCDs differ more on it */
     double ffb_speed[8] = {1, 1, 1, 1, 1, 1, 1, 1};
     int t1_skip = 0, t1_skip_len = 0;
@@ -150,6 +158,10 @@ struct h2y_ctx {
     int opt_groups = 0;        /* "groups": at most this many frame groups (power of two; 1 = off); 0 = by the frame's size (groups_cap()) */
     bool opt_cols8 = true;     /* "cols8": 8-column tiles for half input where the planes allow */
     int opt_bal_mode = 0;      /* "balance": 0 adaptive, 1 off, 2 fixed */
+    int opt_tail = 2;           /* "tail": 0 auto (groups of at least kTailMinFrames frames), 1 on (two frames suffice), 2 off (the default: measured
+                                   neutral on 64 x 4K -- the blocks' finish times close up from +-30 us to +-15 us of a 1.5 ms launch, and the
+                                   frame's own dealing costs what that saves) */
+    bool opt_bal_blocks = true; /* adaptive: by the speed of every block ("adaptive"), or of the XCDs only ("xcd") */
     uint32_t opt_bal_mask = 0xFFu;
     double opt_bal_rho = 1.0;
     int opt_fir = 0;           /* "fir": 0 auto, 1 two-pass (4:4:4 scratch + k_fir420), 2 fused single pass where it applies */
@@ -422,8 +434,8 @@ int out_kind_of(const h2y_desc *d)
     return d->chroma_resampler_type == 0 ? H2Y_OUT_420BOX : H2Y_OUT_444TMP;
 }
 
-/* after a launch whose block clocks came back: speed of each XCD = the share its blocks had / the time they took;
- * the next launch's slice ranges follow the speeds (run_frames()) */
+/* after a launch whose block clocks came back: speed of each XCD = the share its blocks had / the time they took, and the
+ * same for every block by itself; the next launch's slice ranges follow the speeds (run_frames()) */
 void balance_update(h2y_ctx *ctx)
 {
     if (!ctx->b->bal_pending) return;
@@ -442,6 +454,29 @@ void balance_update(h2y_ctx *ctx)
         ctx->bal_speed[x] = ctx->bal_have ? 0.5 * ctx->bal_speed[x] + 0.5 * v : v;
     }
     ctx->bal_have = true;
+    /* per block: a launch ends with its slowest BLOCK, and blocks of one XCD differ too (+-0.5 % of a launch, half of it the
+     * same blocks from launch to launch).  Lighter smoothing than for the XCDs: one block's time is noisier than the mean of 32 */
+    const int grid = ctx->b->bal_grid;
+    if (grid > 0 && grid <= 1024 && ctx->b->h_btime && (int)ctx->b->bal_bwork.size() == grid) {
+        std::vector<double> bs((size_t)grid);
+        double bmean = 0.0;
+        for (int b = 0; b < grid; b++) {
+            const double t = ctx->b->h_btime[b];
+            if (!(t > 0.0)) return;
+            bs[(size_t)b] = ctx->b->bal_bwork[(size_t)b] / t;
+            bmean += bs[(size_t)b] / grid;
+        }
+        const bool have = ctx->bal_bgrid == grid && ctx->bal_bgroups == ctx->b->bal_groups && (int)ctx->bal_bspeed.size() == grid;
+        if (!have) ctx->bal_bspeed.assign((size_t)grid, 1.0);
+        for (int b = 0; b < grid; b++) {
+            double v = bs[(size_t)b] / bmean;
+            if (v < 0.75) v = 0.75;
+            if (v > 1.25) v = 1.25;
+            ctx->bal_bspeed[(size_t)b] = have ? 0.65 * ctx->bal_bspeed[(size_t)b] + 0.35 * v : v;
+        }
+        ctx->bal_bgrid = grid;
+        ctx->bal_bgroups = ctx->b->bal_groups;
+    }
 }
 
 /* the table of transfer function fn on the device (built on the host the first time it is asked for) */
@@ -783,6 +818,10 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
          * the measured speed of its XCD says (block i of a group runs on XCD i % 8 under xcd_layout).  "off": the even
          * round-robin dealing of frame_walk. */
         const uint32_t *d_slice_ranges = nullptr;
+        uint32_t range_stride = 0;
+        bool tail_on = false;
+        uint32_t tail_slices = 0;
+        std::vector<double> bwork;
         double work[8] = {1, 1, 1, 1, 1, 1, 1, 1};
         if (xcd_layout && ctx->opt_bal_mode != 1) {
             const uint32_t G = (uint32_t)grid / (uint32_t)groups, nslices = (g.tiles + 63u) / 64u;
@@ -792,11 +831,36 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
                 mean += sp[x] / 8.0;
             }
             for (int x = 0; x < 8; x++) work[x] = sp[x] / mean;
-            std::vector<uint32_t> r((size_t)G + 1u);
-            slice_ranges(sp, G, nslices, r.data()); /* h2y_walk.h */
+            /* per block when this grid shape has been measured (adaptive mode), else per XCD: one table for every group */
+            const bool per_block = ctx->opt_bal_mode == 0 && ctx->opt_bal_blocks && ctx->bal_bgrid == grid && ctx->bal_bgroups == groups &&
+                                   (int)ctx->bal_bspeed.size() == grid && (size_t)groups * (G + 1u) <= kRangeWords;
+            std::vector<uint32_t> r(per_block ? (size_t)groups * (G + 1u) : (size_t)G + 1u);
+            bwork.assign((size_t)grid, 1.0);
+            if (per_block) {
+                std::vector<double> w(G);
+                for (uint32_t gi = 0; gi < (uint32_t)groups; gi++) {
+                    for (uint32_t i = 0; i < G; i++) w[i] = ctx->bal_bspeed[walk_block_of(gi, i, (uint32_t)groups)];
+                    slice_ranges_w(w.data(), G, nslices, r.data() + (size_t)gi * (G + 1u)); /* h2y_walk.h */
+                }
+                range_stride = G + 1u;
+            } else slice_ranges(sp, G, nslices, r.data());
+            /* the dynamic last frame (k_fused_t1): its eight shards' boundaries ride behind the ranges */
+            const int per_group = nf / groups;
+            tail_on = t1 && ctx->opt_tail != 2 && nf % groups == 0 && per_group >= (ctx->opt_tail == 1 ? 2 : kTailMinFrames) && groups <= 16 &&
+
+                      /* a block holds 64 chunks of H2Y_TAIL_CHUNK slices at most (H2Y_TAIL_QLEN): the group's G blocks must be able to take the
+                       * whole frame with room to spare, however unevenly they draw (any block may end up in the common pool) */
+                      (uint64_t)(nslices / H2Y_TAIL_CHUNK + 96u) * 2u <= 64ull * G && G >= 8u;
+            tail_slices = nslices;
+            for (uint32_t gi = 0; gi < (uint32_t)groups; gi++) {
+                const uint32_t *rg = r.data() + (size_t)(per_block ? gi : 0u) * (G + 1u);
+                for (uint32_t i = 0; i < G; i++) bwork[walk_block_of(gi, i, (uint32_t)groups)] = (double)(rg[i + 1] - rg[i]) * (double)G / (double)nslices;
+            }
             if (!ctx->b->h_ranges) {
                 HIP_TRY(ctx, hipHostMalloc((void **)&ctx->b->h_ranges, 2 * kRangeWords * sizeof(uint32_t), hipHostMallocMapped));
                 HIP_TRY(ctx, hipHostGetDevicePointer((void **)&ctx->b->hd_ranges, ctx->b->h_ranges, 0));
+                HIP_TRY(ctx, hipHostMalloc((void **)&ctx->b->h_btime, 1024 * sizeof(float), hipHostMallocMapped));
+                HIP_TRY(ctx, hipHostGetDevicePointer((void **)&ctx->b->hd_btime, ctx->b->h_btime, 0));
             }
             if (r.size() > kRangeWords) return fail(ctx, H2Y_EINVAL, "internal: %zu slice ranges", r.size());
             /* The kernels read these tables IN PLACE from mapped pinned memory: a slot may only be rewritten once every launch that
@@ -835,6 +899,17 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         a.xcd_layout = xcd_layout ? 1u : 0u;
         a.block_clock = clocks ? ctx->b->d_clock : nullptr;
         a.slice_ranges = d_slice_ranges;
+        a.range_stride = range_stride;
+        a.tail_ctr = nullptr;
+        a.tail_slices = 0;
+        if (tail_on && d_slice_ranges) {
+            if (!ctx->b->d_tail) {
+                HIP_TRY(ctx, hipMalloc((void **)&ctx->b->d_tail, 16 * H2Y_TAIL_WORDS * sizeof(uint32_t)));
+                HIP_TRY(ctx, hipMemsetAsync(ctx->b->d_tail, 0, 16 * H2Y_TAIL_WORDS * sizeof(uint32_t), ctx->stream)); /* k_stats_final clears it from here on */
+            }
+            a.tail_ctr = ctx->b->d_tail;
+            a.tail_slices = tail_slices;
+        }
         a.redo_count = t1 ? ctx->b->d_redo : nullptr;
         a.low_flag = approx ? ctx->b->d_low : nullptr;
         a.frames = ctx->b->d_frames + ctx->slot_base + f0;
@@ -878,8 +953,9 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
             static const char *const kPipe[] = {"RUNTIME", "PQ_IDENT", "PQ_NORM", "LUT16", "PQ_IDENT", "PQ_NORM", "NONE", "TFN"};
             const char *mode = var.mode == H2Y_MODE_YCBCR ? "YCBCR" : var.mode == H2Y_MODE_YDZDX ? "YDZDX" : var.mode == H2Y_MODE_IDENTITY ? "IDENTITY" : "YPQRS";
             char buf[192];
-            snprintf(buf, sizeof buf, "%s<%s,%s,%s,%s%s>%s groups=%d xcd=%d", ctx->last_name, kIn[var.in_kind], kOut[var.out_kind], mode,
-                     kPipe[var.pipe], var.cols8 ? ",COLS8" : "", out_kind == H2Y_OUT_444TMP ? "+k_fir420" : "", groups, xcd_layout ? 1 : 0);
+            snprintf(buf, sizeof buf, "%s<%s,%s,%s,%s%s>%s groups=%d xcd=%d%s", ctx->last_name, kIn[var.in_kind], kOut[var.out_kind], mode,
+                     kPipe[var.pipe], var.cols8 ? ",COLS8" : "", out_kind == H2Y_OUT_444TMP ? "+k_fir420" : "", groups, xcd_layout ? 1 : 0,
+                     a.tail_ctr ? " tail=1" : "");
             ctx->last_variant = buf;
         }
         HIP_TRY(ctx, h2y_launch_fused(var, grid, ctx->stream, a));
@@ -902,11 +978,17 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
         fa.grid = grid;
         static_assert(sizeof(frame_stats) >= 8 * sizeof(float), "the XCD run times ride in one frame_stats entry");
         fa.xcd_time = reinterpret_cast<float *>(ctx->b->fs_out + fstats_offset + n); /* the caller's copy of the statistics takes one entry more */
+        fa.tail_ctr = a.tail_ctr;
+        fa.tail_n = groups * (int)H2Y_TAIL_WORDS;
+        fa.block_time = clocks && d_slice_ranges && ctx->b->fs_out == ctx->b->m_fstats ? ctx->b->hd_btime : nullptr; /* (enqueued batches: what the host reads in h2y_batch_finish) */
         HIP_TRY(ctx, h2y_launch_stats_final(nf, ctx->stream, fa));
         if (clocks) {
             ctx->b->bal_slot = fstats_offset + n;
             ctx->b->bal_pending = true;
             for (int x = 0; x < 8; x++) ctx->b->bal_work[x] = work[x];
+            ctx->b->bal_grid = fa.block_time ? grid : 0;
+            ctx->b->bal_groups = groups;
+            ctx->b->bal_bwork = bwork;
         }
         if (out_kind == H2Y_OUT_444TMP) {
             HIP_TRY(ctx, hipEventRecord(ctx->ev_fused[half], ctx->stream));
@@ -1146,7 +1228,9 @@ int h2y_ctx_create(int device, h2y_ctx **out)
  *   "t1"      "0" | "1"                 binary32 first tier off / on (default on)
  *   "groups"  "0" | "1" .. "64"         at most this many frame groups (rounded down to a power of two; 1 = off); "0": by the frame's size (default)
  *   "cols8"   "0" | "1"                 8-column thread tiles for half input (default on)
- *   "balance" "adaptive" | "off" | "<xcd mask>,<ratio>"   weighted rounds across XCDs (default adaptive)
+ *   "balance" "adaptive" | "xcd" | "off" | "<xcd mask>,<ratio>"   slices by measured block speed / XCD speed only / even / fixed XCD weights (default adaptive)
+ *   "tail"    "off" | "auto" | "on"     k_fused_t1: the last frame of every frame group drawn dynamically by the blocks that finish first
+ *                                       (auto: groups of eight frames or more; on: two suffice; default off: measured neutral)
  *   "fir"     "auto" | "twopass" | "fused"   how the FIR resampler runs (default auto)
  *   "firsync" "0" | "1" .. "1024"       k_fir_fused: the waves of a block meet at a barrier every so many steps (power of two; 0 = never; default "auto": 2, or 0 while many pixels go to the exact tiers) */
 int h2y_ctx_set_option(h2y_ctx *ctx, const char *name, const char *value)
@@ -1168,17 +1252,23 @@ int h2y_ctx_set_option(h2y_ctx *ctx, const char *name, const char *value)
         while (2 * p <= v && p < 64) p *= 2;
         ctx->opt_groups = v ? p : 0;
     } else if (!strcmp(name, "balance")) {
-        if (!strcmp(value, "adaptive")) ctx->opt_bal_mode = 0;
+        if (!strcmp(value, "adaptive")) { ctx->opt_bal_mode = 0; ctx->opt_bal_blocks = true; }
+        else if (!strcmp(value, "xcd")) { ctx->opt_bal_mode = 0; ctx->opt_bal_blocks = false; } /* round 2's form: A/B timing */
         else if (!strcmp(value, "off")) ctx->opt_bal_mode = 1;
         else {
             char *end = nullptr;
             const unsigned long mm = strtoul(value, &end, 0);
             const double r = (end && *end == ',') ? atof(end + 1) : 0.0;
-            if (!(mm & 0xFFu) || (mm & 0xFFu) == 0xFFu || !(r > 1.0)) return fail(ctx, H2Y_EINVAL, "balance: want adaptive, off or <mask>,<ratio > 1>");
+            if (!(mm & 0xFFu) || (mm & 0xFFu) == 0xFFu || !(r > 1.0)) return fail(ctx, H2Y_EINVAL, "balance: want adaptive, xcd, off or <mask>,<ratio > 1>");
             ctx->opt_bal_mode = 2;
             ctx->opt_bal_mask = (uint32_t)(mm & 0xFFu);
             ctx->opt_bal_rho = r;
         }
+    } else if (!strcmp(name, "tail")) {
+        if (!strcmp(value, "auto")) ctx->opt_tail = 0;
+        else if (!strcmp(value, "on")) ctx->opt_tail = 1;
+        else if (!strcmp(value, "off")) ctx->opt_tail = 2;
+        else return fail(ctx, H2Y_EINVAL, "tail: want auto, on or off");
     } else if (!strcmp(name, "fir")) {
         if (!strcmp(value, "auto")) ctx->opt_fir = 0;
         else if (!strcmp(value, "twopass")) ctx->opt_fir = 1;
@@ -1207,6 +1297,8 @@ void h2y_ctx_destroy(h2y_ctx *ctx)
         (void)hipFree(b.d_low);
         (void)hipFree(b.d_clock);
         (void)hipHostFree(b.h_ranges);
+        (void)hipHostFree(b.h_btime);
+        (void)hipFree(b.d_tail);
         (void)hipFree(b.d_unit_rows);
         (void)hipHostFree(b.h_unit_rows);
         (void)hipFree(b.d_fstats);

@@ -66,6 +66,11 @@ struct fused_args {
     const uint32_t *slice_ranges; /* xcd_layout, loop-form kernels: [gridDim.x / groups + 1] first 64-tile slice of every block of a group
                                      (the last entry = slices per frame): block i of a group takes slices [r[i], r[i+1]) of each of the
                                      group's frames; NULL = the round-robin dealing of frame_walk */
+    uint32_t *tail_ctr = nullptr; /* not NULL (k_fused_t1, slice ranges in force): the last frame of every group is drawn dynamically (h2y_walk.h,
+                                 "The dynamic last frame"): [groups][H2Y_TAIL_WORDS] counters and bits, zero at launch (k_stats_final clears them again) */
+    uint32_t tail_slices = 0; /* slices of such a frame */
+    uint32_t range_stride = 0; /* 0: one table for every group; else the words from one group's table to the next's (each group cut by
+                                 the speeds of its own blocks) */
     const void *table;        /* pq_recA[NREC] then pq_recB[NREC] */
     const void *table_src, *table_dst; /* k_fused, generic transfer pair (pp.convert_transfer == 2): the two stages' tables in the same
                                           format (tfn_build_table), or NULL for a stage that is the identity */
@@ -113,6 +118,9 @@ struct final_args {
     unsigned long long *block_clock; /* not NULL: fused_args.block_clock of the launch just finished ... */
     int grid;                        /* ... its grid ... */
     float *xcd_time;                 /* ... and where block 0 leaves the mean run time (us) of the blocks of each XCD [8]; clears the finish entries */
+    float *block_time = nullptr;     /* not NULL: [min(grid, 1024)] every block's own run time (us), for the per-block balancing */
+    uint32_t *tail_ctr = nullptr;    /* not NULL: fused_args.tail_ctr, cleared for the next launch ... */
+    int tail_n = 0;                  /* ... its words */
 };
 
 struct fir_args {

@@ -305,7 +305,8 @@ __device__ __forceinline__ void walk_init(frame_walk &fw, const fused_args &a)
 {
     walk_args wa;
     wa.groups = a.groups; wa.xcd_layout = a.xcd_layout;
-    wa.chunks_per_frame = a.chunks_per_frame; wa.n_frames = a.n_frames;
+    wa.chunks_per_frame = a.chunks_per_frame;
+    wa.n_frames = a.n_frames;
     fw.init(wa, blockIdx.x, gridDim.x);
 }
 /* this wave's slot in the per-frame arrays: [frame][block of the group][wave] */
@@ -360,8 +361,9 @@ __device__ __forceinline__ bool block_range(const fused_args &a, const frame_wal
 {
     first = count = 0;
     if (!a.slice_ranges) return false;
-    first = __builtin_amdgcn_readfirstlane(a.slice_ranges[fw.bi]);
-    count = __builtin_amdgcn_readfirstlane(a.slice_ranges[fw.bi + 1u]) - first;
+    const uint32_t *r = a.slice_ranges + (size_t)a.range_stride * (uint32_t)fw.f; /* (before the frame loop fw.f is the group's number) */
+    first = __builtin_amdgcn_readfirstlane(r[fw.bi]);
+    count = __builtin_amdgcn_readfirstlane(r[fw.bi + 1u]) - first;
     return true;
 }
 /* draw a number: lane 0 adds to the counter, the other lanes to scratch words of their own (no branch) */
@@ -674,6 +676,7 @@ __global__ __launch_bounds__(H2Y_LOOP_THREADS) void k_fused2(fused_args a)
  * (sixteen wave lists) of the CU's 160 KB of LDS.
  */
 #define H2Y_T1_THREADS 1024
+#define H2Y_TAIL_QLEN 64 /* chunks of the dynamic last frame a block can draw (h2y_walk.h): 64 x 16 slices = a sixteenth of a 4K frame */
 #define H2Y_REDO_CAP 128 /* list entries per wave: up to 63 left over plus the 64 one tile can add */
 struct redo_ctx {        /* what redo_pass needs, handed over in LDS so that the call carries two pointers */
     const frame_io *frames;
@@ -705,6 +708,40 @@ __device__ __forceinline__ void tile_t1(const pix_params &pp, const t1_sens &sn,
         }
         row_pack<OUT_KIND, true>(pp, row, Y, Cb, Cr, o, sb, sr);
     }
+}
+
+/* the same with the first tier's verdict: the lanes whose tile holds a pixel it could not settle (the tile must be redone).
+ * Written as the tile loop's own row code is -- three records of a pixel on their way before the first is used, the guards'
+ * lane masks ORed in scalar registers and pinned after every pixel: left alone, the compiler keeps every pixel's operands
+ * alive to the end of the tile, and the loop that calls this spilled a quarter of its registers. */
+template <int OUT_KIND, int MODE, int PIPE>
+__device__ __forceinline__ uint64_t tile_t1_flag(const pix_params &pp, const t1_sens &sn, const pq_rec1 *t1, const tile_in &v, tile_out &o)
+{
+    uint32_t sb[2], sr[2];
+    uint64_t redo_m = 0;
+#pragma unroll
+    for (int row = 0; row < 2; row++) {
+        const float(&gv)[4] = row ? v.g1 : v.g0;
+        const float(&bv)[4] = row ? v.b1 : v.b0;
+        const float(&rv)[4] = row ? v.r1 : v.r0;
+        uint32_t Y[4], Cb[4], Cr[4];
+#pragma unroll
+        for (int col = 0; col < 4; col++) {
+            const float Gn = norm1<PIPE>(pp, 0, gv[col]), Bn = norm1<PIPE>(pp, 1, bv[col]), Rn = norm1<PIPE>(pp, 2, rv[col]);
+            const pq_rec1 cg = pq_t1_fetch(Gn, t1), cb = pq_t1_fetch(Bn, t1), cr = pq_t1_fetch(Rn, t1);
+            __builtin_amdgcn_sched_barrier(0);
+            bool ug, ub, ur;
+            const float g = pix_scale(pq_t1_eval(Gn, cg, &ug), pp.mulY, pp.addY);
+            const float b = pix_scale(pq_t1_eval(Bn, cb, &ub), pp.mulC, pp.addC);
+            const float r = pix_scale(pq_t1_eval(Rn, cr, &ur), pp.mulC, pp.addC);
+            bool ra, rb;
+            pix_matrix_t1<MODE>(pp, sn, g, b, r, ug | ub | ur, Y[col], Cb[col], Cr[col], &ra, &rb);
+            redo_m |= __builtin_amdgcn_ballot_w64(ra) | __builtin_amdgcn_ballot_w64(rb);
+            asm volatile("" : "+s"(redo_m));
+        }
+        row_pack<OUT_KIND, true>(pp, row, Y, Cb, Cr, o, sb, sr);
+    }
+    return redo_m;
 }
 
 /* one tile per lane out of the wave's list: entries [first, first + cnt).
@@ -769,10 +806,18 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
     __shared__ pix_params s_pp;
     __shared__ redo_ctx s_rc;
     __shared__ uint32_t s_claim[H2Y_CLAIM_FRAMES], s_scratch[WAVE];
+    __shared__ uint32_t s_tq[H2Y_TAIL_QLEN + 3], s_tbounds[1]; /* the dynamic last frame: the block's chunks, its drawing state (part, parts found empty), its ticket; the XCDs' runs */
     {
         stage16<H2Y_T1_THREADS, H2Y_T1_NREC>(a.table1, s_t1);
         stage_table<H2Y_T1_THREADS>(a.table, s_t2);
         if (threadIdx.x < H2Y_CLAIM_FRAMES) s_claim[threadIdx.x] = 0u;
+        if (threadIdx.x < H2Y_TAIL_QLEN) s_tq[threadIdx.x] = 0xFFFFFFFFu; /* not drawn yet */
+        if (threadIdx.x == 0) {
+            s_tq[H2Y_TAIL_QLEN] = (blockIdx.x * 37u) & (H2Y_TAIL_PARTS - 1u); /* the part of the dynamic frame this block starts at (37 is odd: the blocks spread over all of them) */
+            s_tq[H2Y_TAIL_QLEN + 1] = 0u;
+            s_tq[H2Y_TAIL_QLEN + 2] = 0u;
+        }
+        if (a.tail_ctr && threadIdx.x == 0) s_tbounds[0] = a.tail_slices;
     }
     const pix_params pp = with_assumed(a.pp, a.assumed);
     t1_sens sn = a.sn;
@@ -831,11 +876,78 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
     uint32_t fo = 0;   /* ordinal of the frame among the group's: its counter is s_claim[fo] */
     uint32_t tick = 0; /* the slice in hand, if hold: of the frame the loop is at (or about to enter) */
     bool hold = false; /* (have implies hold: v is tick's tile; a redo pass drops the data, not the slice) */
+    uint32_t dyn_carry = 0, dyn_t0_next = 0; /* the dynamic frame: first tile of a slice drawn from the frame before it / of the slice asked for */
     walk_init(fw, a);
+    const uint32_t grp = (uint32_t)fw.f; /* the block's group: its first frame */
     uint32_t r_first, r_count;
     const bool ranged = block_range(a, fw, r_first, r_count);
-    for (; fw.f < a.n_frames; fw.advance(), fo++) {
+    /*
+     * The dynamic last frame of the group (h2y_walk.h): same loop, other source of slices.  The BLOCK draws chunks of sixteen
+     * slices from the counters in global memory; ticket t of the block's counter s_tq[QLEN + 2] stands for slice t % 16 of its
+     * chunk t / 16, and s_tq[c] holds chunk c once it is drawn: first slice | count << 24, kTqEmpty when nothing was left.
+     * The wave that holds ticket 16 c reads chunk c (it is there, or about to be) and then draws chunk c + 1: one chunk ahead,
+     * one drawer at a time, the atomic's latency on one wave in sixteen.  A ticket beyond a short last chunk stands for that
+     * chunk's last slice once more (the same bytes again, as for lanes beyond a frame's end).
+     */
+    constexpr uint32_t kTqNone = 0xFFFFFFFFu, kTqEmpty = 0xFFFFFFFEu;
+    volatile uint32_t *const tq = s_tq;
+    uint32_t *const tail_ctr = a.tail_ctr ? a.tail_ctr + grp * H2Y_TAIL_WORDS : nullptr;
+    auto draw_chunk = [&](uint32_t c) { /* one chunk from the counters: by ONE wave at a time (the block's drawing state is in LDS) */
+        tail_state ts;
+        ts.part = tq[H2Y_TAIL_QLEN];
+        ts.tried = tq[H2Y_TAIL_QLEN + 1];
+        const uint32_t n_slices = s_tbounds[0];
+        uint32_t got = kTqEmpty;
+        uint32_t known[2] = {0u, 0u}; /* parts known to be exhausted (bits set by whoever found them so): read once one is met */
+        while (!ts.done()) {
+            if ((known[ts.part >> 5] >> (ts.part & 31u)) & 1u) { ts.skip(); continue; }
+            uint32_t cv = 0u;
+            if (lane == 0) cv = __hip_atomic_fetch_add(tail_ctr + ts.part, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint32_t first, count;
+            if (ts.take(n_slices, __builtin_amdgcn_readfirstlane(cv), &first, &count)) {
+                got = first | (count << 24);
+                break;
+            }
+            uint32_t k0 = 0u, k1 = 0u;
+            if (lane == 0) {
+                k0 = __hip_atomic_fetch_or(tail_ctr + H2Y_TAIL_PARTS + (ts.part >> 5), 1u << (ts.part & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                k1 = __hip_atomic_load(tail_ctr + H2Y_TAIL_PARTS + ((ts.part >> 5) ^ 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            known[ts.part >> 5] = __builtin_amdgcn_readfirstlane(k0) | (1u << (ts.part & 31u));
+            known[(ts.part >> 5) ^ 1u] = __builtin_amdgcn_readfirstlane(k1);
+            ts.skip();
+        }
+        if (lane == 0) {
+            /* (LDS operations of one wave are carried out in the order it issued them: the state is there before the chunk that
+             * tells the next drawer to read it -- no fence: one would also wait for the wave's picture loads and stores) */
+            tq[H2Y_TAIL_QLEN] = ts.part;
+            tq[H2Y_TAIL_QLEN + 1] = ts.tried;
+            asm volatile("" ::: "memory");
+            tq[c] = got;
+        }
+    };
+    /* ticket tk of the dynamic frame -> its slice's first tile; false: the frame is dealt out */
+    auto dyn_tile0 = [&](uint32_t tk, uint32_t &tile0) -> bool {
+        const uint32_t c = tk / H2Y_TAIL_CHUNK, idx = tk % H2Y_TAIL_CHUNK;
+        if (c >= H2Y_TAIL_QLEN) return false; /* (the host sees to it that a block never gets this far: run_frames()) */
+        if (tk == 0u) draw_chunk(0u);          /* the first wave of the block to get here */
+        uint32_t e;
+        while ((e = tq[c]) == kTqNone) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        if (idx == 0u && c + 1u < H2Y_TAIL_QLEN) {
+            if (e == kTqEmpty) { if (lane == 0) tq[c + 1u] = kTqEmpty; }
+            else draw_chunk(c + 1u);
+        }
+        if (e == kTqEmpty) return false;
+        const uint32_t cnt = e >> 24;
+        tile0 = ((e & 0xFFFFFFu) + (idx < cnt ? idx : cnt - 1u)) * WAVE;
+        return true;
+    };
+    for (; fw.f < fw.n_frames; fw.advance(), fo++) {
         const int f = fw.f;
+        const bool dyn = tail_ctr != nullptr && !fw.has_next();                         /* this frame is the group's dynamic one */
+        const bool dyn_n = tail_ctr != nullptr && fw.has_next() && f + 2 * (int)fw.NG >= fw.n_frames; /* the next one is */
+        uint32_t dyn_t0 = 0; /* dyn: first tile of the slice in hand / asked for */
         const frame_io io = uniform_io(a.frames + f);
         const frame_io io_next = uniform_io(a.frames + (fw.has_next() ? f + (int)fw.NG : f)); /* for the prefetch across the frame boundary */
         mm6 mm;
@@ -850,14 +962,19 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
             deal.set(fw, fw.k0, H2Y_T1_THREADS / WAVE);
             deal_n.set(fw, fw.k0_n, H2Y_T1_THREADS / WAVE);
         }
-        if (!hold) {
+        if (dyn) {
+            if (!hold) {
+                tick = wave_claim(&s_tq[H2Y_TAIL_QLEN + 2], s_scratch, true);
+                hold = dyn_tile0(tick, dyn_t0);
+            } else dyn_t0 = dyn_carry; /* the slice was drawn while the previous frame was finishing */
+        } else if (!hold) {
             tick = wave_claim(&s_claim[fo], s_scratch, true);
             hold = tick < deal.total;
         }
         bool more = hold;
         while (more) {
             if (!have) { /* nothing on its way (first tile of the launch, after a redo pass, or a wave that found a frame dealt out) */
-                t_cur = tile_locate(umin32(deal.tile0<H2Y_T1_THREADS>(tick) + lane, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
+                t_cur = tile_locate(umin32((dyn ? dyn_t0 : deal.tile0<H2Y_T1_THREADS>(tick)) + lane, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
                 tile_load<IN_KIND>(io, t_cur, v);
             }
             /* have the data arrive here: entering the loop with loads outstanding would make the loop's
@@ -866,7 +983,7 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
             for (int j = 0; j < 4; j++)
                 asm volatile("" ::"v"(v.g0[j]), "v"(v.b0[j]), "v"(v.r0[j]), "v"(v.g1[j]), "v"(v.b1[j]), "v"(v.r1[j]));
             do {
-                const uint32_t tt = deal.tile0<H2Y_T1_THREADS>(tick) + lane;
+                const uint32_t tt = (dyn ? dyn_t0 : deal.tile0<H2Y_T1_THREADS>(tick)) + lane;
                 tile_pos t = t_cur; /* located one iteration ago, as the prefetch target */
                 t.row1 = true;
                 const void *src[3];
@@ -874,7 +991,7 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
                 uint32_t tick2;
                 tile_pos t2;
                 /* the next slice's number is asked for here and read after row 0, when the prefetch needs it */
-                const uint32_t n1v = wave_claim_issue(&s_claim[fo], s_scratch);
+                const uint32_t n1v = wave_claim_issue(dyn ? &s_tq[H2Y_TAIL_QLEN + 2] : &s_claim[fo], s_scratch);
 
                 tile_out o;
                 uint32_t sb[2], sr[2]; /* 2x2 box: chroma sums of the two blocks */
@@ -972,19 +1089,37 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
                     if (row == 0) { /* row 0 of the next tile, into the registers just read for the last time */
                         { /* (spelled out: through ticket_resolve() the same code came out 3 % slower here) */
                             const uint32_t n1 = __builtin_amdgcn_readfirstlane(n1v);
-                            const bool same = n1 < deal.total;
                             uint32_t tt2;
+                            if (__builtin_expect(dyn, 0)) { /* the dynamic frame: the ticket's slice out of the block's chunks; no frame behind it */
+                                uint32_t t0n = 0;
+                                const bool same = dyn_tile0(n1, t0n);
+                                kind = same ? 1 : 0;
+                                tick2 = same ? n1 : tick;
+                                tt2 = same ? t0n : dyn_t0;
+                                dyn_t0_next = tt2;
+                            } else {
+                            const bool same = n1 < deal.total;
                             if (__builtin_expect(same, 1)) {
                                 kind = 1;
                                 tick2 = n1;
                                 tt2 = deal.tile0<H2Y_T1_THREADS>(n1);
                             } else { /* this frame is dealt out: a slice of the group's next frame, if there is one */
                                 const bool try_next = fw.has_next();
-                                const uint32_t n2 = wave_claim(&s_claim[(fo + 1u) & (H2Y_CLAIM_FRAMES - 1u)], s_scratch, try_next);
-                                const bool nextf = try_next && n2 < deal_n.total;
+                                bool nextf;
+                                uint32_t n2, t0n = 0;
+                                if (dyn_n) { /* ... which is the dynamic one */
+                                    n2 = wave_claim(&s_tq[H2Y_TAIL_QLEN + 2], s_scratch, true);
+                                    nextf = dyn_tile0(n2, t0n);
+                                    dyn_carry = t0n;
+                                } else {
+                                    n2 = wave_claim(&s_claim[(fo + 1u) & (H2Y_CLAIM_FRAMES - 1u)], s_scratch, try_next);
+                                    nextf = try_next && n2 < deal_n.total;
+                                    if (nextf) t0n = deal_n.tile0<H2Y_T1_THREADS>(n2);
+                                }
                                 kind = nextf ? 2 : 0;
                                 tick2 = nextf ? n2 : tick;
-                                tt2 = nextf ? deal_n.tile0<H2Y_T1_THREADS>(n2) : deal.tile0<H2Y_T1_THREADS>(tick);
+                                tt2 = nextf ? t0n : deal.tile0<H2Y_T1_THREADS>(tick);
+                            }
                             }
                             hold = have = kind != 0;
 #pragma unroll
@@ -1020,6 +1155,7 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
                 }
                 more = kind == 1;
                 tick = tick2;
+                if (dyn) dyn_t0 = dyn_t0_next;
             } while (more && n_redo < WAVE);
             if (n_redo >= WAVE) { /* 64 tiles to redo: one per lane */
                 n_redo -= WAVE;
@@ -1390,6 +1526,8 @@ __global__ __launch_bounds__(H2Y_FINAL_THREADS) void k_stats_final(final_args a)
             a.block_clock[2 * b + 1] = 0ull; /* ready for the next launch's atomicMax */
         }
     }
+    if (a.tail_ctr && f == 0)
+        for (int i = (int)threadIdx.x; i < a.tail_n; i += (int)blockDim.x) a.tail_ctr[i] = 0u; /* ready for the next launch */
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
     if (a.redo_count) { /* one add per wave */
@@ -1454,6 +1592,12 @@ __global__ __launch_bounds__(H2Y_FINAL_THREADS) void k_stats_final(final_args a)
                 n++;
             }
             a.xcd_time[x] = n ? (float)sum / (float)n * 0.01f : 0.f; /* 100 MHz ticks -> us */
+        }
+        if (a.block_time) {
+            int t0 = s_min[0];
+#pragma unroll
+            for (int k = 1; k < 8; k++) t0 = min(t0, s_min[k]);
+            for (int b = x; b < nb; b += (int)blockDim.x) a.block_time[b] = (float)(s_finish[b] - t0) * 0.01f;
         }
     }
 }

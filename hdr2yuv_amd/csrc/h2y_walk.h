@@ -87,17 +87,72 @@ struct frame_walk {
 };
 
 /* Slice ranges: r[0 .. G] with r[0] = 0, r[G] = n_slices, block i of a group taking [r[i], r[i+1]); the share of block i
- * is proportional to speed[i % 8], the measured speed of the XCD it runs on under the XCD layout. */
-inline void slice_ranges(const double speed[8], uint32_t G, uint32_t n_slices, uint32_t *r)
+ * is proportional to w[i]: the measured speed of that block (round 3), or of the XCD it runs on (speed[i % 8] under the XCD
+ * layout). */
+inline void slice_ranges_w(const double *w /* [G] */, uint32_t G, uint32_t n_slices, uint32_t *r)
 {
     double tot = 0.0;
-    for (uint32_t i = 0; i < G; i++) tot += speed[i % 8u];
+    for (uint32_t i = 0; i < G; i++) tot += w[i];
     double cum = 0.0;
     for (uint32_t i = 0; i <= G; i++) {
         r[i] = i == G ? n_slices : (uint32_t)(cum / tot * (double)n_slices + 0.5);
-        if (i < G) cum += speed[i % 8u];
+        if (i < G) cum += w[i];
     }
 }
+inline void slice_ranges(const double speed[8], uint32_t G, uint32_t n_slices, uint32_t *r)
+{
+    double w[1024];
+    for (uint32_t i = 0; i < G && i < 1024u; i++) w[i] = speed[i % 8u];
+    slice_ranges_w(w, G, n_slices, r);
+}
+/* the block of the grid that is block i of group g under the XCD layout (the inverse of frame_walk::init) */
+H2Y_FN uint32_t walk_block_of(uint32_t g, uint32_t i, uint32_t NG) { return (((i >> 3) * NG + g) << 3) | (i & 7u); }
+
+/*
+ * The dynamic last frame (round 3).  With every frame dealt in fixed shares a launch ends when its slowest block ends, and
+ * the blocks' finish times spread over 2-4 % of a launch however the shares are cut (the spread is not the same from one
+ * launch to the next: shares cut by every block's own measured speed ran no faster than shares cut by its XCD's).  So the
+ * LAST frame of every group is not dealt at all: a block that has finished its shares of the other frames draws slices of
+ * that frame from counters in global memory until none is left -- blocks that finish early do more of it.  Draws on one
+ * word go one after the other, 0.4 us each under load (measured: 2 025 draws per counter made the frame take 330 us instead
+ * of 45), so a BLOCK draws sixteen slices at a time -- its waves share them through a ticket in LDS, the next chunk is asked
+ * for while this one is worked on -- and the frame is cut in sixty-four parts with a counter each (sixteen draws per counter
+ * and 4K frame, at device scope): a block starts at a part of its own and goes round; a part found exhausted is marked in
+ * two words of bits next to the counters, read before every draw, so that at the end of the frame a block does not ask
+ * sixty-four empty counters in turn.  tail_state is the whole rule; the kernels add the atomics, tools/walk_check.cpp plays
+ * it with random interleavings.
+ */
+#define H2Y_TAIL_CHUNK 32u /* slices a BLOCK draws at a time: two per wave of a 1024-thread block (a draw takes microseconds under load:
+                              with sixteen the drawing wave could not stay a chunk ahead of the other fifteen) */
+#define H2Y_TAIL_PARTS 64u /* counters per group: the frame's slices cut in as many equal parts */
+#define H2Y_TAIL_WORDS (H2Y_TAIL_PARTS + 2u) /* per group: the counters, then two words of "part is exhausted" bits */
+struct tail_state {
+    uint32_t part, tried; /* the part being drawn from; parts found (or known to be) exhausted so far */
+    H2Y_FN void init(uint32_t start) { part = start & (H2Y_TAIL_PARTS - 1u); tried = 0; }
+    H2Y_FN bool done() const { return tried >= H2Y_TAIL_PARTS; }
+    H2Y_FN void range(uint32_t n_slices, uint32_t *lo, uint32_t *hi) const
+    {
+        *lo = (uint32_t)(((uint64_t)n_slices * part) / H2Y_TAIL_PARTS);
+        *hi = (uint32_t)(((uint64_t)n_slices * (part + 1u)) / H2Y_TAIL_PARTS);
+    }
+    H2Y_FN void skip() /* the part is exhausted: on to the next one */
+    {
+        tried++;
+        part = (part + 1u) & (H2Y_TAIL_PARTS - 1u);
+    }
+    /* `c` = what the part's counter held before this block's increment: the c-th chunk of H2Y_TAIL_CHUNK slices of the part
+     * (the last one may be shorter); false: the part is exhausted (the caller marks it so and skip()s) */
+    H2Y_FN bool take(uint32_t n_slices, uint32_t c, uint32_t *first, uint32_t *count) const
+    {
+        uint32_t lo, hi;
+        range(n_slices, &lo, &hi);
+        const uint64_t start = (uint64_t)lo + (uint64_t)c * H2Y_TAIL_CHUNK;
+        if (start >= hi) return false;
+        *first = (uint32_t)start;
+        *count = hi - (uint32_t)start < H2Y_TAIL_CHUNK ? hi - (uint32_t)start : H2Y_TAIL_CHUNK;
+        return true;
+    }
+};
 
 } // namespace h2y
 #endif

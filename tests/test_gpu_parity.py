@@ -1318,6 +1318,64 @@ def test_dark_frames_dense_below_the_tables(oracle, path):
         c.close()
 
 
+@pytest.mark.parametrize("content", ["uniform", "bars", "dark", "low"])
+@pytest.mark.parametrize("out", ["box", "444", "fir_twopass"])
+def test_dynamic_last_frame(oracle, content, out):
+    """k_fused_t1 with the last frame of every frame group drawn dynamically from the counters in global memory (h2y_walk.h,
+    "The dynamic last frame"; "tail" = "on": two frames per group suffice): batches of 12 and 5 frames at one, two and four
+    groups, second round on the statistics hint; uniform noise, letterbox bars (rows of zeros: every tile of them joins the
+    redo lists in that frame), dark frames (samples below the tables) and a frame with a sample <= -1 in its LAST frame (the
+    floor assumed for the batch is wrong there: it must be found from the tail's own minimum and the frame redone)."""
+    import torch
+
+    rng = np.random.default_rng({"uniform": 1, "bars": 2, "dark": 3, "low": 4}[content] * 97 + len(out))
+    w, hh = 1024, 256  # 32 chunks a frame: batches of five frames and more fill the 256-block grid (the XCD layout needs whole rounds)
+    kw = dict(dst_depth=12, dst_matrix=h.MATRIX_BT2020NC)
+    if out == "444":
+        kw.update(chroma=h.CHROMA_444, dst_matrix=h.MATRIX_YDZDX, dst_depth=10)
+    elif out == "fir_twopass":
+        kw.update(resampler=1, dst_depth=10)
+    else:
+        kw.update(resampler=0)
+    d = h.make_desc(w, hh, **kw)
+    od = _to_oracle_desc(d)
+    for n, groups in ((12, 2), (12, 4), (5, 1), (16, 8)):
+        host = []
+        for k in range(n):
+            planes = _rand_planes(rng, w, hh, h.SAMPLE_F32)
+            if content == "bars":
+                for p in planes:
+                    p[: 12 * w] = 0.0
+                    p[-12 * w:] = 0.0
+                    p[12 * w], p[12 * w + 1] = 0.0, 1.0
+            elif content == "dark":  # squared: 0.02 % of the samples below the tables (denser, and the context moves to k_fused2)
+                planes = [(p * p).astype(np.float32) for p in planes]
+                for p in planes:
+                    p[0], p[1] = 0.0, 1.0
+            elif content == "low" and k >= n - groups:
+                planes[1][w * 40 + 7] = np.float32(-1.5)  # in the dynamic frames only
+            host.append(planes)
+        want = [oracle.convert_frame(od, fr) for fr in host]
+        c = h.Context(0)
+        try:
+            c.set_option("tail", "on")
+            c.set_option("groups", str(groups))
+            if out == "fir_twopass":
+                c.set_option("fir", "twopass")
+            dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in host]
+            for rnd in range(3):
+                dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda") for _ in host]
+                torch.cuda.synchronize()
+                c.convert_batch(d, dev_in, dev_out)
+                assert c.last_kernel_name() == "k_fused_t1", c.last_kernel_variant()
+                assert " tail=1" in c.last_kernel_variant(), c.last_kernel_variant()
+                for f in range(n):
+                    got = dev_out[f].cpu().numpy().view(np.uint16)
+                    assert np.array_equal(got, want[f]), (content, out, n, groups, rnd, f, int(np.count_nonzero(got != want[f])))
+        finally:
+            c.close()
+
+
 def test_cli_runs_the_reference_test_sh_lines(tmp_path, oracle):
     """test.sh:21-57 and :66-74 flag for flag (tests/cli_lines.py): no range flag anywhere, so the reference's destination is
     VIDEO range (in_pic zeroed at hdr2yuv.cpp:765, copied to the destination at :296-297) -- also on the .exr line, where

@@ -92,6 +92,91 @@ static void check_ranges(uint32_t G, uint32_t n_slices, const double sp[8])
     }
 }
 
+/* per-block weights: every group's table is a partition with shares within one slice of their proportion, and
+ * walk_block_of() is the inverse of frame_walk::init()'s numbering under the XCD layout */
+static void check_block_ranges(uint32_t grid, uint32_t groups, uint32_t n_slices, unsigned seed)
+{
+    const uint32_t G = grid / groups;
+    std::vector<double> bs(grid);
+    unsigned s = seed;
+    for (uint32_t b = 0; b < grid; b++) {
+        s = s * 1664525u + 1013904223u;
+        bs[b] = 0.75 + 0.5 * (double)(s >> 8) / 16777216.0;
+    }
+    bool bad = false;
+    std::vector<int> hit(grid, 0);
+    for (uint32_t g = 0; g < groups && !bad; g++) {
+        std::vector<double> w(G);
+        double tot = 0;
+        for (uint32_t i = 0; i < G; i++) {
+            const uint32_t b = walk_block_of(g, i, groups);
+            if (b >= grid) { bad = true; break; }
+            hit[b]++;
+            walk_args wa;
+            wa.groups = groups; wa.xcd_layout = 1; wa.chunks_per_frame = 16; wa.n_frames = (int)groups;
+            frame_walk fw;
+            fw.init(wa, b, grid);
+            if ((uint32_t)fw.f != g || fw.bi != i) bad = true;
+            w[i] = bs[b];
+            tot += w[i];
+        }
+        std::vector<uint32_t> r(G + 1);
+        slice_ranges_w(w.data(), G, n_slices, r.data());
+        if (r[0] != 0 || r[G] != n_slices) bad = true;
+        for (uint32_t i = 0; i < G && !bad; i++) {
+            if (r[i + 1] < r[i]) bad = true;
+            if (std::fabs((double)(r[i + 1] - r[i]) - w[i] / tot * n_slices) > 1.0) bad = true;
+        }
+    }
+    for (uint32_t b = 0; b < grid && !bad; b++) bad = hit[b] != 1;
+    n_cfg++;
+    if (bad) {
+        n_bad++;
+        if (n_bad < 20) printf("BAD block ranges grid %u groups %u slices %u\n", grid, groups, n_slices);
+    }
+}
+
+/* the dynamic last frame: blocks draw chunks from the sixty-four counters in a random interleaving, skipping the parts they
+ * know to be exhausted (bits that lag behind the truth by a random amount), until tail_state says done -- every slice of the
+ * frame must come out exactly once */
+static void check_tail(uint32_t n_slices, uint32_t n_blocks, unsigned seed)
+{
+    bool bad = false;
+    std::vector<int> seen(n_slices, 0);
+    uint32_t ctr[H2Y_TAIL_PARTS] = {0};
+    uint64_t bits = 0;
+    std::vector<tail_state> w(n_blocks);
+    unsigned s = seed;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return s >> 8; };
+    for (uint32_t i = 0; i < n_blocks; i++) w[i].init(i * 37u);
+    uint32_t live = n_blocks;
+    long guard = 0;
+    while (live && !bad) {
+        const uint32_t i = rnd() % n_blocks;
+        if (w[i].done()) continue;
+        const uint64_t known = (rnd() & 1u) ? bits : 0; /* a stale view now and then */
+        if ((known >> w[i].part) & 1u) w[i].skip();
+        else {
+            uint32_t first, count;
+            if (w[i].take(n_slices, ctr[w[i].part]++, &first, &count)) {
+                if (count < 1 || count > H2Y_TAIL_CHUNK || first + count > n_slices) bad = true;
+                else for (uint32_t k = 0; k < count; k++) seen[first + k]++;
+            } else {
+                bits |= 1ull << w[i].part;
+                w[i].skip();
+            }
+        }
+        if (w[i].done()) live--;
+        if (++guard > 64L * (long)(n_slices + 64u * n_blocks) + 1000000L) bad = true;
+    }
+    for (uint32_t k = 0; k < n_slices && !bad; k++) bad = seen[k] != 1;
+    n_cfg++;
+    if (bad) {
+        n_bad++;
+        if (n_bad < 20) printf("BAD tail slices %u blocks %u\n", n_slices, n_blocks);
+    }
+}
+
 int main()
 {
     const uint32_t grids[] = {1, 7, 8, 16, 24, 60, 64, 256};
@@ -109,6 +194,13 @@ int main()
     for (const auto &sp : speeds)
         for (uint32_t G : {8u, 16u, 32u, 64u, 128u, 256u})
             for (uint32_t ns : {1u, 7u, 8u, 63u, 256u, 4050u, 16200u, 64800u}) check_ranges(G, ns, sp);
+    for (uint32_t ns : {1u, 7u, 8u, 63u, 64u, 65u, 1000u, 4050u, 16200u, 64800u})
+        for (uint32_t nb : {1u, 8u, 16u, 128u, 256u}) check_tail(ns, nb, ns * 131u + nb);
+    for (uint32_t grid : {8u, 16u, 64u, 256u, 512u, 1024u})
+        for (uint32_t groups = 1; groups <= 32; groups *= 2) {
+            if (grid % (8 * groups)) continue;
+            for (uint32_t ns : {1u, 63u, 4050u, 16200u, 64800u}) check_block_ranges(grid, groups, ns, grid * 31u + groups * 7u + ns);
+        }
     printf("%ld configurations, %ld bad\n", n_cfg, n_bad);
     return n_bad ? 1 : 0;
 }

@@ -1,14 +1,14 @@
 #!/bin/bash
 # tools/collect_profiles.sh ROUND  (GPU box, from the repo root) -- the evidence bench.py's figures rest on, into
-# gpurun_out/profiles_ROUND/ (copy what is to be judged into profiles/):
+# gpurun_out/profiles_ROUND/ (tools/publish_profiles.sh copies what is to be judged into profiles/):
 #   bench.json                      the plain bench line (unprofiled)
-#   c2box/ c2fir/ c3/ c4/           rocprofv3 --kernel-trace --stats of the bench command for each workload, then the
+#   c2box/ c2fir/ c3/ c4/ c4fir/ c1/  rocprofv3 --kernel-trace --stats of the bench command for each workload, then the
 #                                   PMC passes (separate runs: counters are never combined with tracing)
 #   summary_*.txt                   tools/pmc_summary.py over each
 #   traffic.json                    HBM bytes per launch of the dominant kernels (2 x FETCH_SIZE + WRITE_SIZE, gfx950 note
-#                                   in MI355X_MICROARCH.md), keyed as bench.py looks them up, with the library's sha256
+#                                   in MI355X_MICROARCH.md), keyed as bench.py looks them up, with the hash of the sources
 set -u
-R=${1:-r02}
+R=${1:-r03}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/profiles_$R
 mkdir -p "$OUT"
@@ -23,6 +23,8 @@ prof c2box
 prof c2fir --resampler fir
 prof c3 --workload C3
 prof c4 --workload C4 --frames 16
+prof c4fir --workload C4 --frames 16 --resampler fir
+prof c1 --workload C1
 python3 - "$OUT" <<'PY'
 import hashlib, json, os, re, sys
 out = sys.argv[1]
@@ -35,9 +37,12 @@ res = {"_how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes
                "per-dispatch average of the dominant kernel; FETCH_SIZE doubled (MI355X_MICROARCH.md: gfx950 reports half the bytes of wide coalesced "
                "16-B/lane reads), both in KiB", "library_sha256": sha, "sources_sha256": bench.sources_sha256()}
 alg = {"c2box": ("C2_box_F64", 15.0 * 3840 * 2160 * 64), "c2fir": ("C2_fir_F64", 15.0 * 3840 * 2160 * 64), "c3": ("C3_box_F64", 18.0 * 3840 * 2160 * 64),
-       "c4": ("C4_box_F16", 9.0 * 7680 * 4320 * 16)}
+       "c4": ("C4_box_F16", 9.0 * 7680 * 4320 * 16), "c4fir": ("C4_fir_F16", 9.0 * 7680 * 4320 * 16), "c1": ("C1_box_F64", 15.0 * 1920 * 1080 * 64)}
 for name, (key, ab) in alg.items():
-    txt = open(os.path.join(out, f"summary_{name}.txt")).read()
+    try:
+        txt = open(os.path.join(out, f"summary_{name}.txt")).read()
+    except OSError:
+        continue
     best = None
     for blk in txt.split("== ")[1:]:
         head = blk.splitlines()[0]
@@ -54,3 +59,7 @@ for name, (key, ab) in alg.items():
 json.dump(res, open(os.path.join(out, "traffic.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY
+# pictures unlike the headline's; transfer pairs at 8 frames per launch; the stream pipeline
+bash tools/contentbench.sh "$OUT/content" > "$OUT/content.txt" 2>&1
+python3 tools/tfbench.py > "$OUT/tfbench.txt" 2>&1
+python3 tools/streambench.py > "$OUT/streambench.txt" 2>&1

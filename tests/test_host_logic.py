@@ -191,3 +191,43 @@ def test_cli_unset_attributes_are_zero_and_dst_copies_src(tmp_path):
     r, kv = _cli_dry(["--synthetic", 0, "--dst_filename", tmp_path / "o.yuv", "--src_pic_width", 64, "--src_pic_height", 32, "--src_bit_depth", 32,
                       "--dst_bit_depth", 10, "--dst_chroma_format_idc", 1, "--dst_matrix_coeffs", 9, "--n_frames", 7, "--gpus", 3])
     assert r.returncode == 0 and kv["gpus"] == "3 (devices 0 1 2)" and kv["frames"] == "7" and kv["frame_bytes"] == "6144"
+
+
+def test_cpu_bench_helper_prints_the_frames_md5s(oracle):
+    """oracle/cpu_bench.py is what bench.py's frame-parallel CPU baseline runs, and what its `verified_frames` are compared
+    with: one md5 per requested frame index, of the very bytes the oracle gives for that frame (also with a transfer pair)."""
+    import hashlib
+    import subprocess
+
+    from oracle import binding as ob
+
+    for extra, kw in (([], {}), (["--src-transfer", "16", "--dst-transfer", "1"], dict(src_transfer=16, dst_transfer=1))):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "cpu_bench.py")] + extra + ["64", "32", "1", "12", "9", "3", "0", "11"],
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, r.stderr[-1000:]
+        lines = r.stdout.split("\n")
+        assert lines[0].split()[0] in ("reference", "port")
+        got = {int(ln.split()[1]): ln.split()[2] for ln in lines[1:] if ln.startswith("md5")}
+        d = ob.make_desc(64, 32, dst_depth=12, dst_matrix=9, resampler=1, **kw)
+        for k in (3, 0, 11):
+            assert got[k] == hashlib.md5(oracle.convert_frame(d, synth_frame(64, 32, k)).tobytes()).hexdigest()
+
+
+def test_bench_counts_gpus_without_touching_them(monkeypatch):
+    """The parent of `bench.py --gpus N` must not initialise the GPU (its children are the ranks): devices are counted from the
+    visibility variables, else from the KFD topology in sysfs; neither imports torch."""
+    import importlib
+
+    sys.modules.pop("bench", None)
+    before = "torch" in sys.modules
+    bench = importlib.import_module("bench")
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2,5")
+    assert bench.visible_gpus() == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert bench.visible_gpus() == 0
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    monkeypatch.delenv("CUDA_VISIBLE_DEVICES", raising=False)
+    monkeypatch.delenv("ROCR_VISIBLE_DEVICES", raising=False)
+    n = bench.visible_gpus()
+    assert n is None or n >= 0
+    assert ("torch" in sys.modules) == before  # importing bench and counting devices pulled no torch in

@@ -170,8 +170,6 @@ struct h2y_ctx {
     double fir_flag_share = 0.0; /* share of the last k_fir_fused batch's pixels (in tiles of eight) the first tier could not settle */
     uint16_t *d_tmp = nullptr;
     size_t tmp_cap = 0;
-    uint16_t *d_up = nullptr; /* (unused since k_inverse420 upsamples inside its blocks; freed for contexts that still hold one) */
-    size_t up_cap = 0;
 
     /* staging for the host-buffer entry */
     void *d_in = nullptr;
@@ -1314,7 +1312,6 @@ void h2y_ctx_destroy(h2y_ctx *ctx)
     (void)hipFree(ctx->d_table1);
     (void)hipFree(ctx->d_table_ext);
     (void)hipFree(ctx->d_tmp);
-    (void)hipFree(ctx->d_up);
     (void)hipFree(ctx->d_in);
     (void)hipFree(ctx->d_out);
     if (ctx->fir_stream) {

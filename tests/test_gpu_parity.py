@@ -1376,6 +1376,21 @@ def test_dynamic_last_frame(oracle, content, out):
             c.close()
 
 
+def test_inverse_frame_argument_errors(ctx):
+    """h2y_inverse_frame / h2y_inverse_420 refuse what the reference cannot do either: matrix_coeffs 0 (convert.cpp:1733-1736
+    exits), chroma formats other than 4:4:4 / 4:2:0, odd 4:2:0 sizes (Subsample420to444 reads rows it never wrote), depths
+    outside 8..16; the context stays usable."""
+    n = 64 * 16
+    planes = [np.zeros(n, np.uint16) for _ in range(3)]
+    for args, code in (((64, 16, 3, 12, 0, 0, 16, 0), 2), ((64, 16, 2, 12, 0, 1, 16, 0), 2), ((66, 16, 1, 12, 0, 1, 16, 1), 1),
+                       ((64, 16, 3, 7, 0, 1, 16, 0), 1), ((64, 16, 1, 12, 0, 1, 17, 1), 1)):
+        with pytest.raises(h.H2YError) as e:
+            ctx.inverse_frame(*args, planes)
+        assert e.value.code == code, (args, str(e.value))
+    out = ctx.inverse_frame(64, 16, 3, 12, 0, 11, 16, 0, planes)  # still works: Y'DzDx of zeros
+    assert len(out) == 3 and out[0].shape == (n,)
+
+
 def test_cli_runs_the_reference_test_sh_lines(tmp_path, oracle):
     """test.sh:21-57 and :66-74 flag for flag (tests/cli_lines.py): no range flag anywhere, so the reference's destination is
     VIDEO range (in_pic zeroed at hdr2yuv.cpp:765, copied to the destination at :296-297) -- also on the .exr line, where

@@ -83,27 +83,33 @@ __device__ __forceinline__ int32_t dot2(uint32_t v, uint32_t k, int32_t acc)
 
 /* Horizontal stage for one row and plane (convert.cpp:291-320): c[0..3] = this lane's four 4:4:4 values (below
  * 2^14); a, b = the 4:2:2 values at its even columns 4L and 4L+2, clamped to [0, maxCV] and truncated.  Integer
- * form of fir_h() (h2y_math.h: exact up to 14 bits), the taps taken two at a time. */
-__device__ __forceinline__ void ff_hstage(const uint32_t (&c)[4], const ff_edges &e, int32_t maxcv, uint32_t &a, uint32_t &b)
+ * form of fir_h() (h2y_math.h: exact up to 14 bits), the taps taken two at a time.
+ * RAWC (the first tier): c[] are pix_matrix_t1()'s raw chroma integers -- signed 16-bit quantities, the code value
+ * minus (Half - 1).  The taps sum to 512, so the offset is one constant in the stage's rounding term: k0 = 512 (Half - 1)
+ * + 256 (without RAWC: 256).  a and b come out as code values either way. */
+template <bool RAWC>
+__device__ __forceinline__ uint32_t ff_pack16(uint32_t lo, uint32_t hi) { return RAWC ? ((lo & 0xFFFFu) | (hi << 16)) : (lo | (hi << 16)); }
+template <bool RAWC>
+__device__ __forceinline__ void ff_hstage(const uint32_t (&c)[4], const ff_edges &e, int32_t maxcv, uint32_t k0, uint32_t &a, uint32_t &b)
 {
-    const uint32_t p13 = c[1] | (c[3] << 16);
+    const uint32_t p13 = ff_pack16<RAWC>(c[1], c[3]);
     uint32_t l1 = from_lane_below(p13); /* columns 4L-3, 4L-1 */
     uint32_t l2 = from_lane_below(l1);  /* columns 4L-7, 4L-5 */
     uint32_t r1 = from_lane_above(p13); /* columns 4L+5, 4L+7 */
     if (e.any) { /* the reference's "picture border logic": indices below 0 read column 0, beyond width-1 the last column */
         const uint32_t c0_below = from_lane_below(c[0]);
-        const uint32_t own0 = c[0] | (c[0] << 16), own3 = c[3] | (c[3] << 16);
+        const uint32_t own0 = ff_pack16<RAWC>(c[0], c[0]), own3 = ff_pack16<RAWC>(c[3], c[3]);
         l1 = e.left0 ? own0 : l1;
         l2 = e.left0 ? own0 : (e.left1 ? (c0_below << 16) : l2); /* 4L-5 = -1 -> column 0, which is the lane below's c[0] */
         r1 = e.right0 ? own3 : r1;
     }
     /* even column i = 4L: 21 (s[i-5] + s[i+5]) - 52 (s[i-3] + s[i+3]) + 159 (s[i-1] + s[i+1]) + 256 s[i] + 256, all over 512 */
-    int32_t sa = (int32_t)((c[0] << 8) + 256u);
+    int32_t sa = (int32_t)((c[0] << 8) + k0);
     sa = dot2(l1, FF_K(-52, 159), sa);                               /* s[4L-3], s[4L-1] */
     sa = dot2(p13, FF_K(159, -52), sa);                              /* s[4L+1], s[4L+3] */
     sa = dot2(__builtin_amdgcn_alignbit(r1, l2, 16), FF_K(21, 21), sa); /* s[4L-5] (high half of l2), s[4L+5] (low half of r1) */
     /* even column i = 4L+2 */
-    int32_t sb = (int32_t)((c[2] << 8) + 256u);
+    int32_t sb = (int32_t)((c[2] << 8) + k0);
     sb = dot2(l1, FF_K(21, -52), sb);   /* s[4L-3], s[4L-1] */
     sb = dot2(p13, FF_K(159, 159), sb); /* s[4L+1], s[4L+3] */
     sb = dot2(r1, FF_K(-52, 21), sb);   /* s[4L+5], s[4L+7] */
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
                 const ycc k = pixel_careful<MODE>(&s_pp, G0, B0, R0);
                 y = k.y; cb = k.cb; cr = k.cr;
             }
-            s_black[0] = y; s_black[1] = cb; s_black[2] = cr;
+            s_black[0] = y; s_black[1] = cb - pp.half_m1; s_black[2] = cr - pp.half_m1; /* chroma raw, as pix_matrix_t1() gives it */
         }
         __syncthreads();
     }
@@ -206,6 +212,7 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
     const uint32_t W = a.width, H = a.height, WQ = a.wq, H2 = H >> 1;
     const uint32_t npix = W * H, ncb = (W >> 1) * (H >> 1);
     const int32_t maxcv = (int32_t)pp.maxCV, clo = (int32_t)pp.clo_s, chi = (int32_t)pp.chi_s; /* float input: down_shift == 0 */
+    const uint32_t hk0 = TIER == FF_TIER_T1 ? 512u * pp.half_m1 + 256u : 256u; /* ff_hstage()'s rounding term: with the raw chroma's offset */
 
     /* a wave's units: u = gw, gw + GW, ...; unit = (frame, segment, strip), strips of one band next to each other
      * so that the sixteen waves of a block fill whole lines of the output between them */
@@ -331,14 +338,15 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
                     const float Gn = norm1<PIPE>(pp, 0, gv[col]), Bn = norm1<PIPE>(pp, 1, bv[col]), Rn = norm1<PIPE>(pp, 2, rv[col]);
                     const pq_rec1 cg = pq_t1_fetch(Gn, s_t1), cb = pq_t1_fetch(Bn, s_t1), cr = pq_t1_fetch(Rn, s_t1);
                     __builtin_amdgcn_sched_barrier(0);
-                    bool ug, ub, ur;
-                    const float g = pix_scale(pq_t1_eval(Gn, cg, &ug), pp.mulY, pp.addY);
-                    const float b = pix_scale(pq_t1_eval(Bn, cb, &ub), pp.mulC, pp.addC);
-                    const float rr = pix_scale(pq_t1_eval(Rn, cr, &ur), pp.mulC, pp.addC);
+                    float mg, mb, mr;
+                    const float g = pix_scale(pq_t1_eval_m(Gn, cg, &mg), pp.mulY, pp.addY);
+                    const float b = pix_scale(pq_t1_eval_m(Bn, cb, &mb), pp.mulC, pp.addC);
+                    const float rr = pix_scale(pq_t1_eval_m(Rn, cr, &mr), pp.mulC, pp.addC);
                     bool ra, rb;
-                    pix_matrix_t1<MODE>(pp, sn, g, b, rr, ug | ub | ur, Y[col], Cb[col], Cr[col], &ra, &rb);
+                    pix_matrix_t1<MODE>(pp, sn, g, b, rr, pq_t1_unsure3(mg, mb, mr), Y[col], Cb[col], Cr[col], &ra, &rb);
                     const uint64_t fm = __builtin_amdgcn_ballot_w64(ra) | __builtin_amdgcn_ballot_w64(rb);
                     if (__builtin_expect(fm != 0, 0)) {
+                        const bool ug = pq_t1_unsure(mg), ub = pq_t1_unsure(mb), ur = pq_t1_unsure(mr);
                         /* some lane's pixel here is not settled: the binary64 tier for this pixel position, all lanes
                          * together (no memory operation in this branch but LDS reads and -- samples below the tables -- scalar
                          * loads).  Only the planes that hold an unsure sample of a flagged lane go through it: a sample the first
@@ -373,8 +381,8 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
                             Y2 = k.y; Cb2 = k.cb; Cr2 = k.cr;
                         }
                         Y[col] = fl ? Y2 : Y[col];
-                        Cb[col] = fl ? Cb2 : Cb[col];
-                        Cr[col] = fl ? Cr2 : Cr[col];
+                        Cb[col] = fl ? Cb2 - pp.half_m1 : Cb[col]; /* raw, as the first tier's */
+                        Cr[col] = fl ? Cr2 - pp.half_m1 : Cr[col];
                         flagged += (uint32_t)__popcll(fm);
                         if (PIPE == H2Y_PIPE_PQ_IDENT) low_m |= __builtin_amdgcn_ballot_w64(fl && min3f(Gn, Bn, Rn) <= -1.0f);
                     }
@@ -385,8 +393,8 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
 #if defined(H2Y_EXP_NOCOMPUTE) && H2Y_EXP_NOCOMPUTE >= 2 /* ... nor the FIR stages: the access pattern alone */
                 n_cb[row][0] = Cb[0]; n_cb[row][1] = Cb[2]; n_cr[row][0] = Cr[0]; n_cr[row][1] = Cr[2];
 #else
-                ff_hstage(Cb, e, maxcv, n_cb[row][0], n_cb[row][1]);
-                ff_hstage(Cr, e, maxcv, n_cr[row][0], n_cr[row][1]);
+                ff_hstage<TIER == FF_TIER_T1>(Cb, e, maxcv, hk0, n_cb[row][0], n_cb[row][1]);
+                ff_hstage<TIER == FF_TIER_T1>(Cr, e, maxcv, hk0, n_cr[row][0], n_cr[row][1]);
 #endif
                 if (row == 0) { /* row 0 of the next step, into the registers just read for the last time */
                     ff_load<IN_KIND>(io.in[0], q0n, v.g0);

@@ -98,8 +98,10 @@ __device__ __forceinline__ void tile_pack(const pix_params &pp, int jb, const ui
     }
 }
 /* the same packing one picture row (four pixels) at a time; sb/sr carry the 2x2 box sums from row 0 to row 1 */
-/* NOSHIFT: write_yuv's down shift is known to be zero (float input: the temporary picture has the output's depth) */
-template <int OUT_KIND, bool NOSHIFT = false>
+/* NOSHIFT: write_yuv's down shift is known to be zero (float input: the temporary picture has the output's depth)
+ * RAWC: the chroma comes raw from pix_matrix_t1() (signed, without "+ Half - 1"; no clamp needed): the offset goes in
+ * once per 2x2 box, as the third operand of the first row's sum */
+template <int OUT_KIND, bool NOSHIFT = false, bool RAWC = false>
 __device__ __forceinline__ void row_pack(const pix_params &pp, int row, const uint32_t (&Y)[4], uint32_t (&Cb)[4], uint32_t (&Cr)[4],
                                          tile_out &o, uint32_t (&sb)[2], uint32_t (&sr)[2])
 {
@@ -108,14 +110,19 @@ __device__ __forceinline__ void row_pack(const pix_params &pp, int row, const ui
     yp[1] = pix_yuv_clamp<NOSHIFT>(pp, Y[2], false) | (pix_yuv_clamp<NOSHIFT>(pp, Y[3], false) << 16);
     if (OUT_KIND == H2Y_OUT_420BOX) {
         if (row == 0) {
-            sb[0] = Cb[0] + Cb[1]; sb[1] = Cb[2] + Cb[3];
-            sr[0] = Cr[0] + Cr[1]; sr[1] = Cr[2] + Cr[3];
+            const uint32_t k4 = RAWC ? pp.half_m1 << 2 : 0u;
+            sb[0] = Cb[0] + Cb[1] + k4; sb[1] = Cb[2] + Cb[3] + k4;
+            sr[0] = Cr[0] + Cr[1] + k4; sr[1] = Cr[2] + Cr[3] + k4;
         } else {
             /* convert.cpp:157-160: (a+b+c+d)/4, unsigned truncation; then write_yuv's clamp */
             o.cb_box = pix_box_clamp<NOSHIFT>(pp, sb[0] + Cb[0] + Cb[1]) | (pix_box_clamp<NOSHIFT>(pp, sb[1] + Cb[2] + Cb[3]) << 16);
             o.cr_box = pix_box_clamp<NOSHIFT>(pp, sr[0] + Cr[0] + Cr[1]) | (pix_box_clamp<NOSHIFT>(pp, sr[1] + Cr[2] + Cr[3]) << 16);
         }
     } else {
+        if (RAWC) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) { Cb[q] += pp.half_m1; Cr[q] += pp.half_m1; }
+        }
         if (OUT_KIND == H2Y_OUT_444) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -706,7 +713,7 @@ __device__ __forceinline__ void tile_t1(const pix_params &pp, const t1_sens &sn,
             const float r = pix_scale(pq_t1(norm1<PIPE>(pp, 2, rv[col]), t1, &ur), pp.mulC, pp.addC);
             (void)pix_matrix_t1<MODE>(pp, sn, g, b, r, ug | ub | ur, Y[col], Cb[col], Cr[col]);
         }
-        row_pack<OUT_KIND, true>(pp, row, Y, Cb, Cr, o, sb, sr);
+        row_pack<OUT_KIND, true, true>(pp, row, Y, Cb, Cr, o, sb, sr);
     }
 }
 
@@ -730,16 +737,16 @@ __device__ __forceinline__ uint64_t tile_t1_flag(const pix_params &pp, const t1_
             const float Gn = norm1<PIPE>(pp, 0, gv[col]), Bn = norm1<PIPE>(pp, 1, bv[col]), Rn = norm1<PIPE>(pp, 2, rv[col]);
             const pq_rec1 cg = pq_t1_fetch(Gn, t1), cb = pq_t1_fetch(Bn, t1), cr = pq_t1_fetch(Rn, t1);
             __builtin_amdgcn_sched_barrier(0);
-            bool ug, ub, ur;
-            const float g = pix_scale(pq_t1_eval(Gn, cg, &ug), pp.mulY, pp.addY);
-            const float b = pix_scale(pq_t1_eval(Bn, cb, &ub), pp.mulC, pp.addC);
-            const float r = pix_scale(pq_t1_eval(Rn, cr, &ur), pp.mulC, pp.addC);
+            float mg, mb, mr;
+            const float g = pix_scale(pq_t1_eval_m(Gn, cg, &mg), pp.mulY, pp.addY);
+            const float b = pix_scale(pq_t1_eval_m(Bn, cb, &mb), pp.mulC, pp.addC);
+            const float r = pix_scale(pq_t1_eval_m(Rn, cr, &mr), pp.mulC, pp.addC);
             bool ra, rb;
-            pix_matrix_t1<MODE>(pp, sn, g, b, r, ug | ub | ur, Y[col], Cb[col], Cr[col], &ra, &rb);
+            pix_matrix_t1<MODE>(pp, sn, g, b, r, pq_t1_unsure3(mg, mb, mr), Y[col], Cb[col], Cr[col], &ra, &rb);
             redo_m |= __builtin_amdgcn_ballot_w64(ra) | __builtin_amdgcn_ballot_w64(rb);
             asm volatile("" : "+s"(redo_m));
         }
-        row_pack<OUT_KIND, true>(pp, row, Y, Cb, Cr, o, sb, sr);
+        row_pack<OUT_KIND, true, true>(pp, row, Y, Cb, Cr, o, sb, sr);
     }
     return redo_m;
 }
@@ -846,7 +853,7 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
             const ycc k = pixel_careful<MODE>(&s_pp, G0, B0, R0);
             y = k.y; cb = k.cb; cr = k.cr;
         }
-        s_black[0] = y; s_black[1] = cb; s_black[2] = cr;
+        s_black[0] = y; s_black[1] = cb - pp.half_m1; s_black[2] = cr - pp.half_m1; /* chroma raw, as pix_matrix_t1() gives it */
     }
     __syncthreads();
 
@@ -1023,13 +1030,6 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
 #endif
                     }
                     uint32_t Y[4], Cb[4], Cr[4];
-#ifndef H2Y_T1_AHEAD
-#define H2Y_T1_AHEAD 1 /* the three records of a pixel on their way before the first is used: -1.7 % */
-#endif
-#if H2Y_T1_AHEAD == 2
-                    pq_rec1 ng = pq_t1_fetch(norm1<PIPE>(pp, 0, gv[0]), s_t1), nb = pq_t1_fetch(norm1<PIPE>(pp, 1, bv[0]), s_t1),
-                            nr = pq_t1_fetch(norm1<PIPE>(pp, 2, rv[0]), s_t1);
-#endif
                     /* a row of zeros in every lane (letterbox bars)?  One compare per row for ordinary pictures: each lane's
                      * first sample.  Such rows get the black pixel's code values and are not flagged. */
                     bool zrow = false;
@@ -1055,37 +1055,21 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
                         const float Gn = norm1<PIPE>(pp, 0, gv[col]);
                         const float Bn = norm1<PIPE>(pp, 1, bv[col]);
                         const float Rn = norm1<PIPE>(pp, 2, rv[col]);
-                        bool ug, ub, ur;
-#if H2Y_T1_AHEAD == 0
-                        const float g = pix_scale(pq_t1(Gn, s_t1, &ug), pp.mulY, pp.addY);
-                        const float b = pix_scale(pq_t1(Bn, s_t1, &ub), pp.mulC, pp.addC);
-                        const float r = pix_scale(pq_t1(Rn, s_t1, &ur), pp.mulC, pp.addC);
-#elif H2Y_T1_AHEAD == 1
+                        /* the three records of a pixel on their way before the first is used: -1.7 % (one pixel further ahead: no better) */
                         const pq_rec1 cg = pq_t1_fetch(Gn, s_t1), cb = pq_t1_fetch(Bn, s_t1), cr = pq_t1_fetch(Rn, s_t1);
                         __builtin_amdgcn_sched_barrier(0);
-                        const float g = pix_scale(pq_t1_eval(Gn, cg, &ug), pp.mulY, pp.addY);
-                        const float b = pix_scale(pq_t1_eval(Bn, cb, &ub), pp.mulC, pp.addC);
-                        const float r = pix_scale(pq_t1_eval(Rn, cr, &ur), pp.mulC, pp.addC);
-#else
-                        const pq_rec1 cg = ng, cb = nb, cr = nr;
-                        if (col < 3) {
-                            ng = pq_t1_fetch(norm1<PIPE>(pp, 0, gv[col + 1]), s_t1);
-                            nb = pq_t1_fetch(norm1<PIPE>(pp, 1, bv[col + 1]), s_t1);
-                            nr = pq_t1_fetch(norm1<PIPE>(pp, 2, rv[col + 1]), s_t1);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                        const float g = pix_scale(pq_t1_eval(Gn, cg, &ug), pp.mulY, pp.addY);
-                        const float b = pix_scale(pq_t1_eval(Bn, cb, &ub), pp.mulC, pp.addC);
-                        const float r = pix_scale(pq_t1_eval(Rn, cr, &ur), pp.mulC, pp.addC);
-#endif
+                        float mg, mb, mr;
+                        const float g = pix_scale(pq_t1_eval_m(Gn, cg, &mg), pp.mulY, pp.addY);
+                        const float b = pix_scale(pq_t1_eval_m(Bn, cb, &mb), pp.mulC, pp.addC);
+                        const float r = pix_scale(pq_t1_eval_m(Rn, cr, &mr), pp.mulC, pp.addC);
                         bool ra, rb;
-                        pix_matrix_t1<MODE>(pp, sn, g, b, r, ug | ub | ur, Y[col], Cb[col], Cr[col], &ra, &rb);
+                        pix_matrix_t1<MODE>(pp, sn, g, b, r, pq_t1_unsure3(mg, mb, mr), Y[col], Cb[col], Cr[col], &ra, &rb);
                         redo_m |= __builtin_amdgcn_ballot_w64(ra) | __builtin_amdgcn_ballot_w64(rb); /* a ballot of a compare is the compare's own result */
                         /* pin the mask here: left alone, the compiler postpones every pixel's guard arithmetic
                          * to the end of the tile and keeps its operands alive until then (register spills) */
                         asm volatile("" : "+s"(redo_m));
                     }
-                    row_pack<OUT_KIND, true>(pp, row, Y, Cb, Cr, o, sb, sr);
+                    row_pack<OUT_KIND, true, true>(pp, row, Y, Cb, Cr, o, sb, sr);
                     if (row == 0) { /* row 0 of the next tile, into the registers just read for the last time */
                         { /* (spelled out: through ticket_resolve() the same code came out 3 % slower here) */
                             const uint32_t n1 = __builtin_amdgcn_readfirstlane(n1v);

@@ -862,21 +862,35 @@ H2Y_FN float tfn_fast(float x, const pq_recA *__restrict__ A, tfn_cut cut, uint3
     return zero ? bits2f(zero_bits) : one ? bits2f(one_bits) : (float)v;
 }
 
+/* x - floor(x) in [0,1) (v_fract_f32) */
+H2Y_FN float fract_f32(float v)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fractf(v);
+#else
+    float fr = v - __builtin_floorf(v);
+    return fr >= 1.0f ? 0x1.fffffep-1f : fr;
+#endif
+}
 /* ------------------------------------------------------------------------
  * First tier ("T1"): binary32 only, one 16-byte record per sample.
  *
- * value = c0h + w,  w = c0l + u (c1 + u c2)   (all binary32; u exact)
- * over 256 segments per binade (exponent + top 8 mantissa bits; 6401 records,
- * 100 KB).  c0h + c0l is the segment's constant term split in two floats, so the
- * only rounding that matters is the one of w (|w| <= 2^-9.5 of the value): the REAL number
- * c0h + w is within H2Y_T1_RELERR of the reference's double value.  The float
- * s = RN(c0h + w) is therefore the reference's float unless c0h + w lies
- * within that distance of a rounding tie; e = w - (s - c0h) is the exact
- * rounding error of the addition, so the test is |e| >= ulp(s)/2 - delta.
- * About 0.7 % of samples fail it (*unsure); their pixel is redone by the
- * binary64 tier only when its integers are sensitive to a one-ulp change of
- * V (pixel_t1 in the kernels).  Checked exhaustively: every float of the
- * domain that passes the test gives the reference's float (tools/pq_check t1).
+ * 256 segments per binade of the input (exponent + top 8 mantissa bits; 6401 records, 100 KB).  All the
+ * reference's floats of one segment lie in one binade of the OUTPUT (ulp U) -- the few segments in which
+ * the output passes a power of two, and those above 1 + 2^-8, carry a record whose value is NaN (sentinels)
+ * and go to the binary64 tier.  The record holds a float c of that binade (its bit pattern plus one, "cb") and the segment's
+ * polynomial in units of U, measured from c and shifted by delta - 1/2:
+ *     t = (value - c) / U - 1/2 + delta  =  c0 + u (c1 + u c2)     (binary32; u exact)
+ * so that   RN(value) = c + (floor(t) + 1) U,   bit pattern cb + floor(t),   one integer add,
+ * whenever value / U is further than delta from a rounding tie, i.e. fract(t) >= 2 delta: a test against
+ * ONE constant, because t is in ulps already (v_cvt_flr_i32_f32, v_add_u32, v_fract_f32, v_cmp: four
+ * instructions after the polynomial; the earlier form -- c0h + w in floats, the exact rounding error of
+ * that sum against a threshold made from the sum's exponent -- took five).
+ * delta = H2Y_T1_DELTA bounds |t as computed - t of the reference's double| over EVERY float of the
+ * domain (tools/pq_check t1 measures it and checks that every sample passing the test is the
+ * reference's float); about 1 % of samples fail the test (*unsure: the result may be one ulp high); their pixel
+ * is redone by the binary64 tier only when its integers are sensitive to a one-ulp change of V
+ * (pix_matrix_t1).
  * ---------------------------------------------------------------------- */
 #define H2Y_T1_SEG_BITS 8
 #define H2Y_T1_LOW_BITS (23 - H2Y_T1_SEG_BITS)
@@ -885,14 +899,16 @@ H2Y_FN float tfn_fast(float x, const pq_recA *__restrict__ A, tfn_cut cut, uint3
 #define H2Y_T1_BASE ((uint32_t)(127 + H2Y_PQ_EMIN) << H2Y_T1_SEG_BITS)
 /* smallest input of the table: 2^EMIN */
 #define H2Y_T1_DOMAIN_LO 0x1p-24f
-#define H2Y_T1_RELERR 2.9e-10f /* measured max 2.523e-10 over every float of the domain (tools/pq_check t1), +15 % */
-/* mantissa bits of 2 (1 - RELERR 2^25) = 1.980538, rounded down */
-#define H2Y_T1_THR_MANT 0x007D8248u
+/* largest: the segment that starts at 1.0 is the last with a polynomial (values above 10 000 cd/m2 are not pictures; and
+ * with V <= PQ(1 + 2^-8) the chroma integers provably need no clamp: t1_chroma_in_range()) */
+#define H2Y_T1_DOMAIN_HI (1.0f + 0x1p-8f)
+#define H2Y_T1_DELTA 0.0040f /* ulps; measured max 0.00345 over every float of the domain (tools/pq_check t1), +15 % */
 struct alignas(16) pq_rec1 {
-    float c0h, c0l, c1, c2;
+    float cb; /* bit pattern: the base float's + 1 */
+    float c0, c1, c2;
 };
-/* the real-number value of the T1 evaluation, as (c0h, 2^25 w); shared with tools */
-H2Y_FN void pq_t1_parts(uint32_t bits, const pq_rec1 &r, float *c0h, float *w)
+/* the polynomial's variable: the sample's low mantissa bits, centred */
+H2Y_FN float pq_t1_u(uint32_t bits)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
     uint32_t fb; /* one v_and_or_b32 (the compiler splits it into and + or) */
@@ -901,9 +917,23 @@ H2Y_FN void pq_t1_parts(uint32_t bits, const pq_rec1 &r, float *c0h, float *w)
 #else
     float f = bits2f((bits & ((1u << H2Y_T1_LOW_BITS) - 1u)) | 0x3F800000u);
 #endif
-    float u = f - (1.0f + 1.0f / (float)(2 << H2Y_T1_SEG_BITS));
-    *w = __builtin_fmaf(__builtin_fmaf(r.c2, u, r.c1), u, r.c0l);
-    *c0h = r.c0h;
+    return f - (1.0f + 1.0f / (float)(2 << H2Y_T1_SEG_BITS));
+}
+/* t of the comment above, as computed; shared with tools */
+H2Y_FN float pq_t1_t(uint32_t bits, const pq_rec1 &r)
+{
+    const float u = pq_t1_u(bits);
+    return __builtin_fmaf(__builtin_fmaf(r.c2, u, r.c1), u, r.c0);
+}
+H2Y_FN int32_t floor_i32_f32(float f)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    int32_t r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(f));
+    return r;
+#else
+    return f != f ? 0 : (int32_t)__builtin_floorf(f); /* |t| < 2^16 for every record with a polynomial; NaN -> 0 as the instruction does */
+#endif
 }
 /* Byte offset of the sample's record.  The sample is first clamped, as a float, between the two
  * sentinel inputs -- the last float segment below the table and 2.0, the first above it -- so
@@ -926,6 +956,8 @@ H2Y_FN uint32_t pq_t1_offset(float x)
 H2Y_FN pq_rec1 pq_t1_fetch(float x, const pq_rec1 *__restrict__ T)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
+    /* T is in LDS.  Address = (index << 4) + (table - first index * 16) as ONE v_lshl_add_u32; written
+     * out because the compiler prefers shift-right 11, and-not 15, add. */
     typedef const __attribute__((address_space(3))) pq_rec1 *lds_rec;
     const uint32_t tbase = (uint32_t)(uintptr_t)(lds_rec)T - ((H2Y_T1_BASE - 1u) << 4);
     uint32_t seg = f2bits(__builtin_amdgcn_fmed3f(x, bits2f(H2Y_T1_LO_SENTINEL_BITS), 2.0f)) >> H2Y_T1_LOW_BITS;
@@ -939,60 +971,50 @@ H2Y_FN pq_rec1 pq_t1_fetch(float x, const pq_rec1 *__restrict__ T)
     return *reinterpret_cast<const pq_rec1 *>(reinterpret_cast<const char *>(T) + pq_t1_offset(x));
 #endif
 }
+/* *margin = fract(t): the sample is unsure iff it is below H2Y_T1_SURE (a kernel takes the minimum of a pixel's three
+ * margins first: one v_min3_f32 and one compare per pixel instead of three compares).  A sentinel record gives t = 0. */
+#define H2Y_T1_SURE (2.0f * H2Y_T1_DELTA)
+H2Y_FN float pq_t1_eval_m(float x, const pq_rec1 &r, float *margin)
+{
+    const float t = pq_t1_t(f2bits(x), r);
+    *margin = fract_f32(t);
+    return bits2f(f2bits(r.cb) + (uint32_t)floor_i32_f32(t));
+}
+H2Y_FN bool pq_t1_unsure(float margin) { return !(margin >= H2Y_T1_SURE); }
+H2Y_FN bool pq_t1_unsure3(float mg, float mb, float mr)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    float m; /* (margins are never NaN: t of a record is finite for every u) */
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(mg), "v"(mb), "v"(mr));
+    return !(m >= H2Y_T1_SURE);
+#else
+    const float m = mg < mb ? (mg < mr ? mg : mr) : (mb < mr ? mb : mr);
+    return !(m >= H2Y_T1_SURE);
+#endif
+}
 H2Y_FN float pq_t1_eval(float x, const pq_rec1 &r, bool *unsure)
 {
-    float c0h, ws;
-    pq_t1_parts(f2bits(x), r, &c0h, &ws);
-    const float s = __builtin_fmaf(ws, 0x1p-25f, c0h);
-    const float es = __builtin_fmaf(s - c0h, -0x1p25f, ws);
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t tb;
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(tb) : "v"(f2bits(s)), "s"(0x7F800000u), "v"(H2Y_T1_THR_MANT));
-    const float thr = bits2f(tb);
-#else
-    const float thr = bits2f((f2bits(s) & 0x7F800000u) | H2Y_T1_THR_MANT);
-#endif
-    *unsure = !(__builtin_fabsf(es) < thr);
-    return s;
+    float m;
+    const float v = pq_t1_eval_m(x, r, &m);
+    *unsure = pq_t1_unsure(m);
+    return v;
 }
-H2Y_FN float pq_t1(float x, const pq_rec1 *__restrict__ T, bool *unsure)
-{
-    const uint32_t bits = f2bits(x);
-#if defined(__HIP_DEVICE_COMPILE__)
-    /* T is in LDS.  Address = (index << 4) + (table - first index * 16) as ONE v_lshl_add_u32; written
-     * out because the compiler prefers shift-right 11, and-not 15, add. */
-    typedef const __attribute__((address_space(3))) pq_rec1 *lds_rec;
-    const uint32_t tbase = (uint32_t)(uintptr_t)(lds_rec)T - ((H2Y_T1_BASE - 1u) << 4);
-    const uint32_t seg = f2bits(__builtin_amdgcn_fmed3f(x, bits2f(H2Y_T1_LO_SENTINEL_BITS), 2.0f)) >> H2Y_T1_LOW_BITS;
-    uint32_t addr;
-    asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(addr) : "v"(seg), "s"(tbase));
-    const pq_rec1 r = *(lds_rec)(uintptr_t)addr;
-#else
-    const pq_rec1 r = *reinterpret_cast<const pq_rec1 *>(reinterpret_cast<const char *>(T) + pq_t1_offset(x));
-#endif
-    float c0h, ws; /* ws = 2^25 w: the table holds c0l, c1, c2 times 2^25 (exact scaling) */
-    pq_t1_parts(bits, r, &c0h, &ws);
-    const float s = __builtin_fmaf(ws, 0x1p-25f, c0h);       /* RN(c0h + w) */
-    const float es = __builtin_fmaf(s - c0h, -0x1p25f, ws);  /* 2^25 (w - (s - c0h)), exact: |c0h| >= |w| */
-    /* |e| against ulp(s)/2 - delta with delta = RELERR*s <= RELERR * 2^25 * ulp(s)/2: one constant factor
-     * (1 - RELERR*2^25) of ulp(s)/2; times 2^25 that is s's exponent with that factor's mantissa
-     * (1.98...), which v_and_or_b32 builds in one instruction -- hence the scaled w */
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t tb; /* written out for the same reason as in pq_t1_parts(); one operand may be scalar, the other sits in a register */
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(tb) : "v"(f2bits(s)), "s"(0x7F800000u), "v"(H2Y_T1_THR_MANT));
-    const float thr = bits2f(tb);
-#else
-    const float thr = bits2f((f2bits(s) & 0x7F800000u) | H2Y_T1_THR_MANT);
-#endif
-    *unsure = !(__builtin_fabsf(es) < thr); /* NaN (sentinel record) => unsure */
-    return s;
-}
+H2Y_FN float pq_t1(float x, const pq_rec1 *__restrict__ T, bool *unsure) { return pq_t1_eval(x, pq_t1_fetch(x, T), unsure); }
 inline void pq_build_table1(pq_rec1 *T)
 {
     const double wn[3] = {-0.8660254037844386, 0.0, 0.8660254037844386};
+    const pq_rec1 nan_rec = {bits2f(0x7FC00000u), 0.0f, 0.0f, 0.0f}; /* t = 0 whatever u is: value NaN, margin 0 = never sure */
     for (int i = 0; i < H2Y_T1_NSEG; i++) {
+        pq_rec1 &o = T[i + 1]; /* record 0 is the low sentinel */
         int e = H2Y_PQ_EMIN + (i >> H2Y_T1_SEG_BITS);
         int sg = i & ((1 << H2Y_T1_SEG_BITS) - 1);
+        const uint32_t xlo = ((uint32_t)(127 + e) << 23) | ((uint32_t)sg << H2Y_T1_LOW_BITS), xhi = xlo + (1u << H2Y_T1_LOW_BITS) - 1u;
+        if (bits2f(xlo) >= H2Y_T1_DOMAIN_HI) { o = nan_rec; continue; }
+        /* the output's binade: that of the segment's first value; its last may be the next power of two itself (the bit
+         * patterns run on), not more */
+        const uint32_t vlo = f2bits((float)pq_exact_dd(dd{(double)bits2f(xlo), 0.0}).hi), vhi = f2bits((float)pq_exact_dd(dd{(double)bits2f(xhi), 0.0}).hi);
+        if ((vhi >> 23) != (vlo >> 23) && vhi != ((vlo >> 23) + 1u) << 23) { o = nan_rec; continue; }
+        const double inv_u = bits2d((uint64_t)(1023 + 23 + 127 - (int)(vlo >> 23)) << 52); /* 1 / U */
         double scale = bits2d((uint64_t)(1023 + e) << 52);
         double mid = scale * (1.0 + (sg + 0.5) / (1 << H2Y_T1_SEG_BITS));
         double half = scale * (0.5 / (1 << H2Y_T1_SEG_BITS));
@@ -1008,19 +1030,14 @@ inline void pq_build_table1(pq_rec1 *T)
         const dd q1 = dd_add(ev[1], dd_mul_d(q2, -(wn[0] + wn[1])));
         const dd q0 = dd_add(dd_add(ev[0], dd_mul_d(ev[1], -wn[0])), dd_mul_d(q2, wn[0] * wn[1]));
         const double r = (double)(2 << H2Y_T1_SEG_BITS);
-        pq_rec1 &o = T[i + 1]; /* record 0 is the low sentinel */
-        o.c0h = (float)q0.hi;
-        o.c0l = (float)((q0.hi - (double)o.c0h) + q0.lo) * 0x1p25f; /* the three below c0h carry a factor 2^25, see pq_t1() */
-        o.c1 = (float)(q1.hi * r) * 0x1p25f;
-        o.c2 = (float)(q2.hi * r * r) * 0x1p25f;
+        const float c = (float)q0.hi; /* in the segment's range of values: of the output's binade (or its upper end) */
+        o.cb = bits2f(f2bits(c) + 1u);
+        o.c0 = (float)((((q0.hi - (double)c) + q0.lo) * inv_u - 0.5) + (double)H2Y_T1_DELTA);
+        o.c1 = (float)(q1.hi * r * inv_u);
+        o.c2 = (float)(q2.hi * r * r * inv_u);
     }
-    for (int i = 0; i < 2; i++) {
-        pq_rec1 &o = T[i ? H2Y_T1_NSEG + 1 : 0];
-        o.c0h = bits2f(0x7FC00000u);
-        o.c0l = o.c1 = o.c2 = 0.0f;
-    }
+    T[0] = T[H2Y_T1_NSEG + 1] = nan_rec;
 }
-
 /* ------------------------------------------------------------------------
  * Per-frame constants handed to the kernels.
  * ---------------------------------------------------------------------- */
@@ -1102,16 +1119,6 @@ H2Y_FN int32_t x86_i32_f64(double v)
 {
     const int32_t r = sat_i32_f64(v);
     return v != v ? (int32_t)0x80000000 : r;
-}
-/* x - floor(x) in [0,1) (v_fract_f32) */
-H2Y_FN float fract_f32(float v)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_fractf(v);
-#else
-    float fr = v - __builtin_floorf(v);
-    return fr >= 1.0f ? 0x1.fffffep-1f : fr;
-#endif
 }
 /* x - floor(x), in [0,1) (v_fract_f64) */
 H2Y_FN double fract_f64(double v)
@@ -1211,7 +1218,13 @@ H2Y_FN void pix_matrix(const pix_params &pp, float G, float B, float R, uint32_t
  * values came out of pq_t1() "unsure" (it may be one float ulp off), the
  * integers are accepted only if none of the three pre-truncation values is
  * close enough to an integer for such a change to matter (bounds: t1_bounds()).
- * Returns true when the pixel must be redone by the binary64 tier. */
+ * Returns true when the pixel must be redone by the binary64 tier.
+ * The chroma comes out RAW: the truncated integers themselves, signed, in two's complement -- without the
+ * reference's "+ Half - 1" and its unsigned clamp to maxCV (convert.cpp:1200-1212, chroma_clamped()).  For a
+ * pixel this tier settles the clamp never acts (its three PQ values are table values: t1_bounds() proves the
+ * range per launch, or the launch does not use this tier), and the offset is linear: the kernels add it once
+ * per 2x2 box or fold it into the FIR's rounding constant instead of once per sample -- four instructions
+ * per pixel less. */
 struct t1_sens {
     float ty;                 /* luma safe iff |fract(y) - 0.5| < ty                     */
     uint32_t cb_lo, cb_span;  /* chroma unsafe iff (hiword(fract(q)) - lo) >= span (wide) */
@@ -1238,8 +1251,8 @@ H2Y_FN void pix_matrix_t1(const pix_params &pp, const t1_sens &sn, float G, floa
         qb = __builtin_fma((double)(B - tmpF), pp.inv_dcb, 0.5);
         qr = __builtin_fma((double)(R - tmpF), pp.inv_dcr, 0.5);
         Yo = (uint32_t)sat_i32_f32(tmpF); /* unclamped: the caller's pix_yuv_clamp() bounds it below maxCV anyway (yhi_s <= maxCV) */
-        Cbo = chroma_clamped(sat_i32_f64(qb), pp.half_m1, pp.maxCV);
-        Cro = chroma_clamped(sat_i32_f64(qr), pp.half_m1, pp.maxCV);
+        Cbo = (uint32_t)sat_i32_f64(qb);  /* raw: see above */
+        Cro = (uint32_t)sat_i32_f64(qr);
         /* One test for the three values: the high words of their fractional parts against one window --
          * with an unsure sample the wide one (one-ulp sensitivity of any of the three), without one the
          * narrow one inside it (the guard of the reciprocal division; harmless for the luma, whose float
@@ -1259,8 +1272,8 @@ H2Y_FN void pix_matrix_t1(const pix_params &pp, const t1_sens &sn, float G, floa
     }
     /* Y is left unclamped: the caller's pix_yuv_clamp() bounds it below maxCV anyway (yhi_s <= maxCV) */
     Yo = (uint32_t)sat_i32_f32(ylike);
-    Cbo = chroma_clamped(sat_i32_f64(qb), pp.half_m1, pp.maxCV);
-    Cro = chroma_clamped(sat_i32_f64(qr), pp.half_m1, pp.maxCV);
+    Cbo = (uint32_t)sat_i32_f64(qb);
+    Cro = (uint32_t)sat_i32_f64(qr);
     const uint32_t fb = (uint32_t)(d2bits(fract_f64(qb)) >> 32), fr = (uint32_t)(d2bits(fract_f64(qr)) >> 32);
     const bool y_unsafe = !(__builtin_fabsf(fract_f32(ylike) - 0.5f) < sn.ty); /* NaN => unsafe */
     /* YDzDx has no division, so without an unsure sample its chroma needs no guard at all */
@@ -1286,9 +1299,44 @@ H2Y_FN bool pix_matrix_t1(const pix_params &pp, const t1_sens &sn, float G, floa
  * 10 % slack on top.  Returns false when the windows get so wide that most
  * pixels with an unsure sample would be redone anyway (high bit depths). */
 H2Y_FN uint32_t hiword_of(double v) { return (uint32_t)(d2bits(v) >> 32); }
+/* Host: do the chroma integers of every pixel the first tier settles lie in [-(Half - 1), maxCV - (Half - 1)], where
+ * chroma_clamped() is the identity?  Such a pixel's PQ values are table values, V in [PQ(2^-24), PQ(1 + 2^-8)]; interval
+ * arithmetic through the scale step and the matrix, with 0.02 + 1e-5 |q| for every rounding on the way (a code value's
+ * float ulp is 2^-12 at 12 bits, 2^-8 at 16). */
+inline bool t1_chroma_in_range(const pix_params &pp)
+{
+    const double vhi = pq_exact_dd(dd{(double)H2Y_T1_DOMAIN_HI, 0.0}).hi * (1.0 + 1e-6), vlo = pq_exact_dd(dd{(double)H2Y_T1_DOMAIN_LO, 0.0}).hi * (1.0 - 1e-6);
+    auto span = [&](double mul, double add, double *lo, double *hi) {
+        const double a = add + mul * vlo, b = add + mul * vhi;
+        *lo = (a < b ? a : b) - 1e-3 - 1e-6 * __builtin_fabs(a < b ? a : b);
+        *hi = (a < b ? b : a) + 1e-3 + 1e-6 * __builtin_fabs(a < b ? b : a);
+    };
+    double glo, ghi, clo, chi;
+    span(pp.mulY, pp.addY, &glo, &ghi);
+    span(pp.mulC, pp.addC, &clo, &chi);
+    double qlo[2], qhi[2];
+    if (pp.mode == H2Y_MODE_YCBCR) {
+        if (!(pp.kr >= 0 && pp.kg >= 0 && pp.kb >= 0 && pp.kb <= 1 && pp.kr <= 1 && pp.inv_dcb > 0 && pp.inv_dcr > 0)) return false;
+        /* d = B - tmpF = (1 - kb) B - kr R - kg G - 0.5 (and the same with R) */
+        const double db_hi = (1 - pp.kb) * chi - pp.kr * clo - pp.kg * glo - 0.5, db_lo = (1 - pp.kb) * clo - pp.kr * chi - pp.kg * ghi - 0.5;
+        const double dr_hi = (1 - pp.kr) * chi - pp.kb * clo - pp.kg * glo - 0.5, dr_lo = (1 - pp.kr) * clo - pp.kb * chi - pp.kg * ghi - 0.5;
+        qhi[0] = db_hi * pp.inv_dcb + 0.5; qlo[0] = db_lo * pp.inv_dcb + 0.5;
+        qhi[1] = dr_hi * pp.inv_dcr + 0.5; qlo[1] = dr_lo * pp.inv_dcr + 0.5;
+    } else if (pp.mode == H2Y_MODE_YDZDX) {
+        qhi[0] = qhi[1] = (chi - glo) * 0.5 + 0.5;
+        qlo[0] = qlo[1] = (clo - ghi) * 0.5 + 0.5;
+    } else return false;
+    const double top = (double)pp.maxCV - (double)pp.half_m1, bot = -(double)pp.half_m1;
+    for (int k = 0; k < 2; k++) {
+        const double hi = qhi[k] + 0.02 + 1e-5 * __builtin_fabs(qhi[k]), lo = qlo[k] - 0.02 - 1e-5 * __builtin_fabs(qlo[k]);
+        if (!(hi < top + 1.0 && lo > bot - 1.0)) return false; /* truncation towards zero */
+    }
+    return true;
+}
 inline bool t1_bounds(const pix_params &pp, t1_sens *sn)
 {
     const double u23 = 0x1p-23;
+    if (!t1_chroma_in_range(pp)) return false;
     const double sY = (double)pp.mulY * 1.2 + pp.addY, sC = (double)pp.mulC * 1.2 + pp.addC; /* PQ < 1.2 on the table's domain */
     const double smax = sY > sC ? sY : sC;
     double Ey, Ecb, Ecr;

@@ -79,6 +79,7 @@ int main(int argc, char **argv)
                     : pix_matrix_t1<H2Y_MODE_YDZDX>(pp, sn, pix_scale(vg, pp.mulY, pp.addY), pix_scale(vb, pp.mulC, pp.addC), pix_scale(vr, pp.mulC, pp.addC), vunc, Ya, Cba, Cra);
                 if (need2) { r++; continue; }
                 Ya = Ya < pp.maxCV ? Ya : pp.maxCV; /* the T1 form leaves the maxCV clamp of Y to pix_yuv_clamp() */
+                Cba += pp.half_m1; Cra += pp.half_m1; /* ... and gives the chroma raw: offset by the kernels, NO clamp (t1_chroma_in_range() says none is needed: checked here) */
                 float G = pix_scale(eg, pp.mulY, pp.addY), Bv = pix_scale(eb, pp.mulC, pp.addC), R = pix_scale(er, pp.mulC, pp.addC);
                 if (c.mode == H2Y_MODE_YCBCR) pix_matrix<H2Y_MODE_YCBCR, true>(pp, G, Bv, R, Ye, Cbe, Cre, &dummy);
                 else pix_matrix<H2Y_MODE_YDZDX, true>(pp, G, Bv, R, Ye, Cbe, Cre, &dummy);

@@ -166,7 +166,7 @@ struct h2y_ctx {
     double opt_bal_rho = 1.0;
     int opt_fir = 0;           /* "fir": 0 auto, 1 two-pass (4:4:4 scratch + k_fir420), 2 fused single pass where it applies */
     int opt_fir_sync = -1;     /* "firsync": k_fir_fused's blocks meet at a barrier every so many steps (power of two; 0 = never);
-                                  -1 = by the pictures: every second step, never while the first tier passes many pixels on */
+                                  -1 = by the pictures: every step, never while the first tier passes many pixels on */
     double fir_flag_share = 0.0; /* share of the last k_fir_fused batch's pixels (in tiles of eight) the first tier could not settle */
     uint16_t *d_tmp = nullptr;
     size_t tmp_cap = 0;
@@ -596,10 +596,12 @@ int run_frames(h2y_ctx *ctx, const h2y_desc *d, const frame_io *frames, int n, c
             fa.seg_rows = seg_rows;
             fa.units_per_frame = upf;
             fa.total_units = (uint32_t)units;
-            /* In step (k_fir_fused, "In step"): every second step -- unless the pictures keep sending pixels to the exact tiers
-             * (each such pixel holds its wave for a microsecond, and in step all sixteen wait with it: a picture with 0.02 % of
-             * its samples below the tables ran in 2.75 ms in step, 2.37 out of step; the usual picture 1.74 and 1.93) */
-            const int fsync = ctx->opt_fir_sync >= 0 ? ctx->opt_fir_sync : (ctx->fir_flag_share > kFirSyncMaxFlagged ? 0 : 2);
+            /* In step (k_fir_fused, "In step"): every step (round 2's kernel: every second; with a fifth of the step's instructions
+             * gone since, meeting every step is 0.4-1.7 % ahead, tools/firsyncbench.sh) -- unless the pictures keep sending pixels
+             * to the exact tiers (each such pixel holds its wave for a microsecond, and in step all sixteen wait with it: a
+             * picture with 0.02 % of its samples below the tables ran in 2.75 ms in step, 2.37 out of step; the usual picture
+             * 1.74 and 1.93) */
+            const int fsync = ctx->opt_fir_sync >= 0 ? ctx->opt_fir_sync : (ctx->fir_flag_share > kFirSyncMaxFlagged ? 0 : 1);
             fa.sync_mask = fsync > 0 ? (uint32_t)fsync - 1u : ~0u;
             fa.table = ctx->d_table;
             fa.table1 = ctx->d_table1;
@@ -1230,7 +1232,7 @@ int h2y_ctx_create(int device, h2y_ctx **out)
  *   "tail"    "off" | "auto" | "on"     k_fused_t1: the last frame of every frame group drawn dynamically by the blocks that finish first
  *                                       (auto: groups of eight frames or more; on: two suffice; default off: measured neutral)
  *   "fir"     "auto" | "twopass" | "fused"   how the FIR resampler runs (default auto)
- *   "firsync" "0" | "1" .. "1024"       k_fir_fused: the waves of a block meet at a barrier every so many steps (power of two; 0 = never; default "auto": 2, or 0 while many pixels go to the exact tiers) */
+ *   "firsync" "0" | "1" .. "1024"       k_fir_fused: the waves of a block meet at a barrier every so many steps (power of two; 0 = never; default "auto": 1, or 0 while many pixels go to the exact tiers) */
 int h2y_ctx_set_option(h2y_ctx *ctx, const char *name, const char *value)
 {
     if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");

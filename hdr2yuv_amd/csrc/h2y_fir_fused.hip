@@ -216,14 +216,23 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
 
     /* a wave's units: u = gw, gw + GW, ...; unit = (frame, segment, strip), strips of one band next to each other
      * so that the sixteen waves of a block fill whole lines of the output between them */
-    for (uint32_t u = gw; u < a.total_units; u += GW) {
+    /* The launch's arguments are read where a unit begins and where it ends, through a pointer the compiler cannot see through
+     * (the kernel-argument segment, laundered): read once at the top, a dozen of them stay in scalar registers across the step
+     * loop, which does not use them, while the loop's own plane pointers were spilled (twelve lane reads a step). */
+    typedef const __attribute__((address_space(4))) firf_args *args_ptr;
+    args_ptr ap = (args_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ap));
+    const uint32_t total_units = ap->total_units, sync_mask = ap->sync_mask;
+    for (uint32_t u = gw; u < total_units; u += GW) {
+        asm volatile("" : "+s"(ap));
         /* (uniform values; the divisions run on the vector unit, so say so) */
-        const uint32_t f = __builtin_amdgcn_readfirstlane(u / a.units_per_frame), r = u - f * a.units_per_frame;
-        const uint32_t seg = __builtin_amdgcn_readfirstlane(r / a.n_strips), strip = r - seg * a.n_strips;
-        const frame_io io = uniform_io(a.frames + f);
-        uint32_t j0 = seg * a.seg_rows, j1 = j0 + a.seg_rows < H2 ? j0 + a.seg_rows : H2;   /* chroma rows [j0, j1) are this unit's */
-        if (a.unit_rows) { /* the host's own cut of this (frame, strip) column (weights by XCD speed) */
-            const uint32_t rw = __builtin_amdgcn_readfirstlane(a.unit_rows[u]);
+        const uint32_t upf = ap->units_per_frame, nst = ap->n_strips, seg_rows = ap->seg_rows;
+        const uint32_t f = __builtin_amdgcn_readfirstlane(u / upf), r = u - f * upf;
+        const uint32_t seg = __builtin_amdgcn_readfirstlane(r / nst), strip = r - seg * nst;
+        const frame_io io = uniform_io(ap->frames + f);
+        uint32_t j0 = seg * seg_rows, j1 = j0 + seg_rows < H2 ? j0 + seg_rows : H2;   /* chroma rows [j0, j1) are this unit's */
+        if (ap->unit_rows) { /* the host's own cut of this (frame, strip) column (weights by XCD speed) */
+            const uint32_t rw = __builtin_amdgcn_readfirstlane(ap->unit_rows[u]);
             j0 = rw & 0xFFFFu;
             j1 = rw >> 16;
         }
@@ -237,7 +246,7 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
         const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(io.out, 0, (int)((npix + 2u * ncb) * 2u), 0x00020000);
 #endif
         ff_edges e;
-        e.any = __builtin_amdgcn_readfirstlane((uint32_t)(strip == 0u) | (uint32_t)(strip + 1u == a.n_strips));
+        e.any = __builtin_amdgcn_readfirstlane((uint32_t)(strip == 0u) | (uint32_t)(strip + 1u == nst));
         e.left0 = qxu == 0;
         e.left1 = qxu == 1;
         e.right0 = qxu == (int32_t)WQ - 1;
@@ -264,7 +273,7 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
              * picture at about the same time -- one DRAM page after the other instead of sixteen places at once (4K x 64
              * frames: 1.90-1.95 ms per launch without, 1.74 every second step -- tools/firsyncbench.sh).  Waves whose units differ in length, or that
              * have none left, just meet less often: a barrier only waits for the waves still running. */
-            if (((s - s_begin) & a.sync_mask) == 0u) __builtin_amdgcn_s_barrier();
+            if (((s - s_begin) & sync_mask) == 0u) __builtin_amdgcn_s_barrier();
             const uint32_t q0n = 2u * (s + 1u < H2 - 1u ? s + 1u : H2 - 1u) * WQ + qx; /* the next step's rows (the last rows again once the picture ends) */
             uint32_t yp[2][2], n_cb[2][2], n_cr[2][2]; /* new 4:2:2 values: [row][column 4L / 4L+2] */
 #pragma unroll
@@ -462,11 +471,13 @@ __global__ __launch_bounds__(FF_THREADS) void k_fir_fused(firf_args a)
                 mm.hi[c] = mm.hi[c] <= 0.0f ? 1.175494351e-38f : mm.hi[c];
             }
         }
-        const size_t slot = (size_t)f * a.units_per_frame + r;
-        wave_store_mm(mm, a.partial + slot * 6);
+        asm volatile("" : "+s"(ap));
+        const uint32_t f_end = __builtin_amdgcn_readfirstlane(u / ap->units_per_frame); /* (again, rather than carried through the loop) */
+        const size_t slot = (size_t)u; /* = f * units_per_frame + r */
+        wave_store_mm(mm, ap->partial + slot * 6);
         if (lane == 0) {
-            a.redo_count[slot] = flagged >> 3; /* in tiles of eight pixels, the unit the host steers by */
-            if (PIPE == H2Y_PIPE_PQ_IDENT && a.low_flag && low_m != 0) a.low_flag[f] = 1u;
+            ap->redo_count[slot] = flagged >> 3; /* in tiles of eight pixels, the unit the host steers by */
+            if (PIPE == H2Y_PIPE_PQ_IDENT && ap->low_flag && low_m != 0) ap->low_flag[f_end] = 1u;
         }
     }
     /* NO BARRIER MAY FOLLOW THE UNIT LOOP.  The pacing s_barrier inside the step loop is executed a different number of times by

@@ -556,7 +556,7 @@ __global__ __launch_bounds__(H2Y_LOOP_THREADS) void k_fused2(fused_args a)
     block_clock_start(a);
     const uint32_t W = a.width, H = a.height;
     const uint32_t lane = threadIdx.x & (WAVE - 1);
-    tile_in v;         /* the tile being worked on; refilled row by row with the next one */
+    tile_in v;         /* the tile being worked on */
     tile_pos t_cur;    /* and where it is */
     bool have = false; /* v holds the tile this wave meets next (uniform) */
     typedef in_traits<IN_KIND> IN;
@@ -863,10 +863,13 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
     uint32_t *const my_list = s_redo[wave];
     uint32_t n_redo = 0; /* entries in my_list (uniform over the wave) */
     /*
-     * Rolling prefetch.  A tile is worked on row by row (four pixels each); as soon as the last pixel
-     * of a row is done, that row's three 16-byte loads of the NEXT tile are issued into the registers
-     * just freed.  Each load is in flight for about half a tile's arithmetic, needs no second set of
-     * registers and no copies.
+     * Prefetch.  The loop is bound by how many bytes it has on their way from memory, not by its arithmetic (a launch with
+     * the arithmetic left out is 3-8 % shorter; a tenth fewer vector instructions changed nothing): sixteen waves per CU are
+     * all the 100 KB table allows, so each must keep a whole tile -- six 16-byte loads per lane, 6 KB per wave -- in flight
+     * while it works on the one before: the next tile's requests go out at the top of the loop body into a second set of
+     * registers, which is copied over the first at the bottom (24 moves, 128 registers in all).  Until round 3 the loop
+     * refilled the tile's own registers row by row as they fell free ("rolling": no second set, no copies, half as many
+     * bytes in flight): 1.474 -> 1.446 ms per 64 x 4K launch on the same box.
      * The loop body is one basic block with a fixed number of memory operations in a fixed order, so
      * every wait is for exactly the loads it needs (memory operations complete in issue order; a
      * store issued conditionally would have to be assumed absent, and its wait would swallow the
@@ -875,7 +878,7 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
      *  - the redo list is appended to with LDS writes only, and working it off happens outside the loop;
      *  - the picture height is even (the host sends odd heights to k_fused).
      */
-    tile_in v;         /* the tile being worked on; refilled row by row with the next one */
+    tile_in v;         /* the tile being worked on */
     tile_pos t_cur;    /* and where it is */
     bool have = false; /* v holds the tile this block meets next (uniform) */
     typedef in_traits<IN_KIND> IN;
@@ -997,9 +1000,58 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
                 int kind;
                 uint32_t tick2;
                 tile_pos t2;
-                /* the next slice's number is asked for here and read after row 0, when the prefetch needs it */
+                /* the next slice's number */
                 const uint32_t n1v = wave_claim_issue(dyn ? &s_tq[H2Y_TAIL_QLEN + 2] : &s_claim[fo], s_scratch);
 
+                tile_in nx; /* the next tile */
+                {
+                        { /* (spelled out: through ticket_resolve() the same code came out 3 % slower here) */
+                            const uint32_t n1 = __builtin_amdgcn_readfirstlane(n1v);
+                            uint32_t tt2;
+                            if (__builtin_expect(dyn, 0)) { /* the dynamic frame: the ticket's slice out of the block's chunks; no frame behind it */
+                                uint32_t t0n = 0;
+                                const bool same = dyn_tile0(n1, t0n);
+                                kind = same ? 1 : 0;
+                                tick2 = same ? n1 : tick;
+                                tt2 = same ? t0n : dyn_t0;
+                                dyn_t0_next = tt2;
+                            } else {
+                            const bool same = n1 < deal.total;
+                            if (__builtin_expect(same, 1)) {
+                                kind = 1;
+                                tick2 = n1;
+                                tt2 = deal.tile0<H2Y_T1_THREADS>(n1);
+                            } else { /* this frame is dealt out: a slice of the group's next frame, if there is one */
+                                const bool try_next = fw.has_next();
+                                bool nextf;
+                                uint32_t n2, t0n = 0;
+                                if (dyn_n) { /* ... which is the dynamic one */
+                                    n2 = wave_claim(&s_tq[H2Y_TAIL_QLEN + 2], s_scratch, true);
+                                    nextf = dyn_tile0(n2, t0n);
+                                    dyn_carry = t0n;
+                                } else {
+                                    n2 = wave_claim(&s_claim[(fo + 1u) & (H2Y_CLAIM_FRAMES - 1u)], s_scratch, try_next);
+                                    nextf = try_next && n2 < deal_n.total;
+                                    if (nextf) t0n = deal_n.tile0<H2Y_T1_THREADS>(n2);
+                                }
+                                kind = nextf ? 2 : 0;
+                                tick2 = nextf ? n2 : tick;
+                                tt2 = nextf ? t0n : deal.tile0<H2Y_T1_THREADS>(tick);
+                            }
+                            }
+                            hold = have = kind != 0;
+#pragma unroll
+                            for (int c = 0; c < 3; c++) src[c] = kind == 2 ? io_next.in[c] : io.in[c];
+                            t2 = tile_locate(umin32(tt2 + lane, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
+                        }
+                    IN::load4q(src[0], t2.q0, nx.g0);
+                    IN::load4q(src[1], t2.q0, nx.b0);
+                    IN::load4q(src[2], t2.q0, nx.r0);
+                    IN::load4q(src[0], t2.q1, nx.g1);
+                    IN::load4q(src[1], t2.q1, nx.b1);
+                    IN::load4q(src[2], t2.q1, nx.r1);
+                    __builtin_amdgcn_sched_barrier(0); /* none of the tile's arithmetic before the requests are out */
+                }
                 tile_out o;
                 uint32_t sb[2], sr[2]; /* 2x2 box: chroma sums of the two blocks */
                 uint64_t redo_m = 0; /* lanes whose tile holds a pixel to redo: the guards' own lane masks, ORed in scalar registers */
@@ -1070,57 +1122,9 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
                         asm volatile("" : "+s"(redo_m));
                     }
                     row_pack<OUT_KIND, true, true>(pp, row, Y, Cb, Cr, o, sb, sr);
-                    if (row == 0) { /* row 0 of the next tile, into the registers just read for the last time */
-                        { /* (spelled out: through ticket_resolve() the same code came out 3 % slower here) */
-                            const uint32_t n1 = __builtin_amdgcn_readfirstlane(n1v);
-                            uint32_t tt2;
-                            if (__builtin_expect(dyn, 0)) { /* the dynamic frame: the ticket's slice out of the block's chunks; no frame behind it */
-                                uint32_t t0n = 0;
-                                const bool same = dyn_tile0(n1, t0n);
-                                kind = same ? 1 : 0;
-                                tick2 = same ? n1 : tick;
-                                tt2 = same ? t0n : dyn_t0;
-                                dyn_t0_next = tt2;
-                            } else {
-                            const bool same = n1 < deal.total;
-                            if (__builtin_expect(same, 1)) {
-                                kind = 1;
-                                tick2 = n1;
-                                tt2 = deal.tile0<H2Y_T1_THREADS>(n1);
-                            } else { /* this frame is dealt out: a slice of the group's next frame, if there is one */
-                                const bool try_next = fw.has_next();
-                                bool nextf;
-                                uint32_t n2, t0n = 0;
-                                if (dyn_n) { /* ... which is the dynamic one */
-                                    n2 = wave_claim(&s_tq[H2Y_TAIL_QLEN + 2], s_scratch, true);
-                                    nextf = dyn_tile0(n2, t0n);
-                                    dyn_carry = t0n;
-                                } else {
-                                    n2 = wave_claim(&s_claim[(fo + 1u) & (H2Y_CLAIM_FRAMES - 1u)], s_scratch, try_next);
-                                    nextf = try_next && n2 < deal_n.total;
-                                    if (nextf) t0n = deal_n.tile0<H2Y_T1_THREADS>(n2);
-                                }
-                                kind = nextf ? 2 : 0;
-                                tick2 = nextf ? n2 : tick;
-                                tt2 = nextf ? t0n : deal.tile0<H2Y_T1_THREADS>(tick);
-                            }
-                            }
-                            hold = have = kind != 0;
-#pragma unroll
-                            for (int c = 0; c < 3; c++) src[c] = kind == 2 ? io_next.in[c] : io.in[c];
-                            t2 = tile_locate(umin32(tt2 + lane, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
-                        }
-                        IN::load4q(src[0], t2.q0, v.g0);
-                        IN::load4q(src[1], t2.q0, v.b0);
-                        IN::load4q(src[2], t2.q0, v.r0);
-                        /* nothing of row 1 may move up past this point: its data is the youngest request */
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
                 }
                 tile_store<OUT_KIND>(io, t, W, H, o);
-                IN::load4q(src[0], t2.q1, v.g1);
-                IN::load4q(src[1], t2.q1, v.b1);
-                IN::load4q(src[2], t2.q1, v.r1);
+                v = nx; /* (24 register moves; waits for the loads asked for at the top) */
                 t_cur = t2;
                 /* tiles to redo (a few lanes of about one wave in four at 12 bits; whole waves on black
                  * bars) go to the wave's list: position = entries so far + flagged lanes below this one */

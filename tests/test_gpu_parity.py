@@ -1590,6 +1590,75 @@ def test_samples_below_the_tables(oracle, path):
         c.close()
 
 
+@pytest.mark.parametrize("path,full", [("t1_box", 0), ("t1_box", 1), ("fir_fused", 0), ("fir_fused", 1), ("ydzdx_box", 0)])
+def test_first_tier_sentinel_segments_and_chroma_range(oracle, path, full):
+    """The first tier (pq_t1, h2y_math.h) answers from a table whose records are sentinels (value NaN: the pixel goes to the
+    binary64 tier) for inputs outside [2^-24, 1 + 2^-8) AND for the few segments in which PQ passes a power of two; and it
+    gives the chroma raw, the offset and the clamp to maxCV left out because t1_chroma_in_range() proved per launch that the
+    clamp cannot act on a pixel it settles.  Samples packed where that could go wrong: exponents uniform over [2^-26, 4)
+    (every binade of the table and both ends), dense runs of consecutive floats across the inputs whose PQ value is
+    2^-7 .. 2^0 (the sentinel segments and their neighbours), values in [1, 2), pixels with one plane near 0 and the others
+    near 1 and the reverse (the chroma's extremes: at full range the raw integer reaches -(Half - 1) and maxCV - (Half - 1)),
+    exact 1.0 and exact 0.0.  Box and one-pass FIR kernels, video and full range, YCbCr and YDzDx."""
+    import torch
+
+    rng = np.random.default_rng(77 + full)
+    w, hh, n = 256, 64, 4
+
+    def pq_inv(v):  # ST 2084 EOTF, double precision: where the table's output passes v
+        m1, m2, c1, c2, c3 = 0.1593017578125, 78.84375, 0.8359375, 18.8515625, 18.6875
+        p = v ** (1.0 / m2)
+        return (max(p - c1, 0.0) / (c2 - c3 * p)) ** (1.0 / m1)
+
+    host = []
+    for k in range(n):
+        planes = [np.exp2(rng.uniform(-26.0, 2.0, hh * w)).astype(np.float32) for _ in range(3)]
+        for flat in planes:
+            pos = 0
+            for e in range(0, 8):  # runs of consecutive floats around PQ^-1(2^-e)
+                x0 = np.float32(min(pq_inv(2.0 ** -e), 1.0))
+                b0 = int(x0.view(np.uint32)) - 700
+                run = (np.arange(1400, dtype=np.uint32) + np.uint32(b0)).view(np.float32)
+                flat[pos:pos + run.size] = run
+                pos += run.size + 37
+            flat[pos:pos + 300] = rng.uniform(1.0, 2.0, 300).astype(np.float32)
+            flat[pos + 300:pos + 340] = 1.0
+            flat[pos + 340:pos + 380] = 0.0
+        # the chroma's extremes, row 40 on: (G, B, R) = (hi, lo, hi), (lo, hi, lo), (hi, hi, lo), (lo, lo, hi) with lo in [2^-24, 2^-20], hi in [0.98, 1.0039)
+        lo = lambda m: np.exp2(rng.uniform(-24.0, -20.0, m)).astype(np.float32)
+        hi = lambda m: rng.uniform(0.98, 1.0039, m).astype(np.float32)
+        for j, pat in enumerate(((1, 0, 1), (0, 1, 0), (1, 1, 0), (0, 0, 1))):
+            for c in range(3):
+                planes[c][(40 + 2 * j) * w:(42 + 2 * j) * w] = (hi if pat[c] else lo)(2 * w)
+        host.append(planes)
+    kw = dict(dst_depth=12, dst_matrix=h.MATRIX_BT2020NC, resampler=0, full_range=full)
+    opts = {}
+    if path == "fir_fused":
+        kw.update(dst_depth=10, resampler=1)
+        opts["fir"] = "fused"
+    elif path == "ydzdx_box":
+        kw.update(dst_matrix=h.MATRIX_YDZDX)
+    d = h.make_desc(w, hh, **kw)
+    od = _to_oracle_desc(d)
+    want = [oracle.convert_frame(od, fr) for fr in host]
+    c = h.Context(0)
+    try:
+        for name, value in opts.items():
+            c.set_option(name, value)
+        dev_in = [[torch.from_numpy(p).cuda() for p in fr] for fr in host]
+        for rnd in range(2):
+            dev_out = [torch.zeros(h.frame_bytes(d) // 2, dtype=torch.int16, device="cuda") for _ in host]
+            torch.cuda.synchronize()
+            c.convert_batch(d, dev_in, dev_out)
+            if rnd == 0:
+                assert c.last_kernel_name() == ("k_fir_fused" if path == "fir_fused" else "k_fused_t1"), c.last_kernel_variant()
+            for f in range(n):
+                got = dev_out[f].cpu().numpy().view(np.uint16)
+                assert np.array_equal(got, want[f]), f"{path} full={full} round {rnd} frame {f}: {np.count_nonzero(got != want[f])} samples differ"
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("firsync", ["0", "1", "2", "8", "auto"])
 def test_fir_fused_waves_in_step(oracle, firsync):
     """k_fir_fused keeps the sixteen waves of a block in step with a barrier every few steps (`firsync`).  The waves do not

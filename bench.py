@@ -417,7 +417,7 @@ def main() -> int:
         arena = torch.empty(len(indices) * 3 * n, dtype=torch.float16 if f16 else torch.float32, device=dev)
         return [synth_cache[key].frame(w, hh, k, f16, into=[arena[(i * 3 + c) * n:(i * 3 + c + 1) * n] for c in range(3)]) for i, k in enumerate(indices)]
 
-    def measure(wl, resampler, frames_in, F, steps, warmup, check=()):
+    def measure(wl, resampler, frames_in, F, steps, warmup, check=(), known=True):
         """One timed pass of workload `wl` over F frames per step (frames_in may hold fewer DISTINCT inputs: they repeat;
         every frame has its own output).  Returns a dict of figures; all ranks call it together.  `check`: output frames whose
         md5 rank 0 takes after the timed loop (r["md5_frames"]), to be held against the CPU reference's frames of the same index."""
@@ -449,8 +449,8 @@ def main() -> int:
         verified, vname, got_md5 = None, None, None
         if rank == 0:
             vname, want = known_md5(stem, is420, resampler)
-            if args.content != "uniform":
-                vname, want = f"none (content {args.content})", None
+            if args.content != "uniform" or not known:
+                vname, want = f"none (content {args.content if known else 'changed'})", None
             if want:
                 got_md5 = hashlib.md5(outs_t[0].cpu().numpy().tobytes()).hexdigest()
                 verified = got_md5 == want
@@ -671,6 +671,53 @@ def main() -> int:
             del din, dout
         except Exception as e:  # a secondary figure never costs the main line
             others["inverse_420"] = {"value": None, "error": str(e)}
+        # pictures unlike the headline's (SURVEY 8d's extra distributions): "squared" = every sample squared (dark-heavy, as HDR
+        # masters are: 0.03 % of the samples fall below the kernels' LDS tables), "bars" = a 2.39:1 letterbox (a quarter of the rows
+        # exact zeros).  Box and FIR each; frame 0 of each pass against the CPU reference's conversion of the same changed frame.
+        if args.workload == "C2" and args.content == "uniform":
+            def change(planes, content, xp):
+                bar = int(round(0.128 * hh))
+                for p_ in planes:
+                    if content == "squared":
+                        p_ *= p_
+                    else:
+                        p_[: bar * w] = 0.0
+                        p_[(hh - bar) * w:] = 0.0
+                        p_[bar * w + 1] = 1.0  # (the planted 1.0 of the generator sat in the first row: ceiling 1 again)
+            for content in ("squared", "bars"):
+                try:
+                    fin = device_frames(desc_kw, range(F))
+                    for fr in fin:
+                        change(fr, content, torch)
+                    torch.cuda.synchronize()
+                    want = {}
+                    if do_cpu:
+                        from hdr2yuv_amd.synth import synth_frame
+                        from oracle import binding as ob
+
+                        try:
+                            impl = ob.Ref(build=False)
+                        except Exception:
+                            impl = ob.Oracle()
+                        planes = synth_frame(w, hh, 0)
+                        change(planes, content, None)
+                        for res in ("box", "fir"):
+                            od = ob.make_desc(width=w, height=hh, dst_depth=desc_kw["dst_depth"], dst_matrix=desc_kw["dst_matrix"], resampler=1 if res == "fir" else 0)
+                            want[res] = hashlib.md5(impl.convert_frame(od, planes).tobytes()).hexdigest()
+                    for res in ("box", "fir"):
+                        r = measure("C2", res, fin, F, sec_steps, sec_warm, [0] if do_cpu else [], known=False)
+                        rf = roofline_of(r)
+                        ok = (r["md5_frames"].get(0) == want[res]) if do_cpu else None
+                        others[f"C2_{res}_{content}"] = {"value": round(r["pixels"] / r["secs"] / 1e6, 1), "unit": "Mpixels/s", "frames_per_step": F, "steps": r["steps"],
+                                                        "kernel": r["kernel"], "variant": r["variant"], "frac": rf["frac"], "achieved_gbs": rf["achieved"],
+                                                        "kernel_ms_min_max": [round(min(r["per_step"]), 4), round(max(r["per_step"]), 4)] if r["per_step"] else None,
+                                                        "frames_redone": r["redone"], "timed_by": rf["timed_by"], "verified": ok,
+                                                        "verify_case": "output frame 0 against the CPU reference's conversion of the same changed frame" if do_cpu else None,
+                                                        "workload": r["text"] + f", chroma {res}, content {content}"}
+                        failed = failed or ok is False
+                    del fin
+                except Exception as e:  # a secondary figure never costs the main line
+                    others[f"C2_{content}"] = {"value": None, "error": str(e)}
         out["others"] = others
         if is420 and args.resampler == "box" and f"{args.workload}_fir" in others:  # round-1 field names, kept
             out["fir_value"] = others[f"{args.workload}_fir"]["value"]

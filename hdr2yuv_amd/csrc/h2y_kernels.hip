@@ -138,28 +138,6 @@ __device__ __forceinline__ void row_pack(const pix_params &pp, int row, const ui
 }
 /* offsets in units of the store (u32x2: a quad of code values; dword: two 4:2:0 chroma samples) from
  * the start of the frame's output: < 2^32 bytes.  W % 4 == 0, so W * H and the chroma plane's size are even. */
-/* k_fused_t1's redo pass: store only the parts of tile o that differ from p (what the first tier left there) */
-template <int OUT_KIND>
-__device__ __forceinline__ void tile_store_changes(const frame_io &io, const tile_pos &t, uint32_t W, uint32_t H, const tile_out &o, const tile_out &p)
-{
-    const uint32_t npix = W * H;
-    if ((o.yp0[0] ^ p.yp0[0]) | (o.yp0[1] ^ p.yp0[1])) gstore<u32x2>(io.out, t.q0, u32x2{o.yp0[0], o.yp0[1]});
-    if (t.row1 && ((o.yp1[0] ^ p.yp1[0]) | (o.yp1[1] ^ p.yp1[1]))) gstore<u32x2>(io.out, t.q1, u32x2{o.yp1[0], o.yp1[1]});
-    if (OUT_KIND == H2Y_OUT_420BOX) {
-        const uint32_t ncb = (W >> 1) * (H >> 1);
-        if (o.cb_box != p.cb_box) gstore<uint32_t>(io.out, (npix >> 1) + t.tt, o.cb_box);
-        if (o.cr_box != p.cr_box) gstore<uint32_t>(io.out, ((npix + ncb) >> 1) + t.tt, o.cr_box);
-    } else {
-        uint16_t *Cbp = OUT_KIND == H2Y_OUT_444 ? io.out + npix : io.tmp_cb;
-        uint16_t *Crp = OUT_KIND == H2Y_OUT_444 ? io.out + 2 * (size_t)npix : io.tmp_cr;
-        if ((o.cbp0[0] ^ p.cbp0[0]) | (o.cbp0[1] ^ p.cbp0[1])) gstore<u32x2>(Cbp, t.q0, u32x2{o.cbp0[0], o.cbp0[1]});
-        if ((o.crp0[0] ^ p.crp0[0]) | (o.crp0[1] ^ p.crp0[1])) gstore<u32x2>(Crp, t.q0, u32x2{o.crp0[0], o.crp0[1]});
-        if (t.row1) {
-            if ((o.cbp1[0] ^ p.cbp1[0]) | (o.cbp1[1] ^ p.cbp1[1])) gstore<u32x2>(Cbp, t.q1, u32x2{o.cbp1[0], o.cbp1[1]});
-            if ((o.crp1[0] ^ p.crp1[0]) | (o.crp1[1] ^ p.crp1[1])) gstore<u32x2>(Crp, t.q1, u32x2{o.crp1[0], o.crp1[1]});
-        }
-    }
-}
 template <int OUT_KIND>
 __device__ __forceinline__ void tile_store(const frame_io &io, const tile_pos &t, uint32_t W, uint32_t H, const tile_out &o)
 {
@@ -687,76 +665,12 @@ __global__ __launch_bounds__(H2Y_LOOP_THREADS) void k_fused2(fused_args a)
 #define H2Y_REDO_CAP 128 /* list entries per wave: up to 63 left over plus the 64 one tile can add */
 struct redo_ctx {        /* what redo_pass needs, handed over in LDS so that the call carries two pointers */
     const frame_io *frames;
-    const pq_rec1 *t1;   /* first-tier table (LDS) */
-    t1_sens sn;
     uint32_t *low_flag;  /* [n_frames]: set when a frame holds a sample <= -1 (subsampled minimum, see the tile loop) */
     uint32_t width, height, wq, wq_magic, tiles_per_frame, tiles_magic;
 };
-/* The first tier's result for one tile, by the very instructions of k_fused_t1's loop (same inline
- * functions, same operands: binary32/64 arithmetic without contraction is deterministic), flags ignored:
- * the bytes the loop stored provisionally. */
-template <int OUT_KIND, int MODE, int PIPE>
-__device__ __forceinline__ void tile_t1(const pix_params &pp, const t1_sens &sn, const pq_rec1 *t1, const tile_in &v, tile_out &o)
-{
-    uint32_t sb[2], sr[2];
-#pragma unroll
-    for (int row = 0; row < 2; row++) {
-        const float(&gv)[4] = row ? v.g1 : v.g0;
-        const float(&bv)[4] = row ? v.b1 : v.b0;
-        const float(&rv)[4] = row ? v.r1 : v.r0;
-        uint32_t Y[4], Cb[4], Cr[4];
-#pragma unroll
-        for (int col = 0; col < 4; col++) {
-            bool ug, ub, ur;
-            const float g = pix_scale(pq_t1(norm1<PIPE>(pp, 0, gv[col]), t1, &ug), pp.mulY, pp.addY);
-            const float b = pix_scale(pq_t1(norm1<PIPE>(pp, 1, bv[col]), t1, &ub), pp.mulC, pp.addC);
-            const float r = pix_scale(pq_t1(norm1<PIPE>(pp, 2, rv[col]), t1, &ur), pp.mulC, pp.addC);
-            (void)pix_matrix_t1<MODE>(pp, sn, g, b, r, ug | ub | ur, Y[col], Cb[col], Cr[col]);
-        }
-        row_pack<OUT_KIND, true, true>(pp, row, Y, Cb, Cr, o, sb, sr);
-    }
-}
-
-/* the same with the first tier's verdict: the lanes whose tile holds a pixel it could not settle (the tile must be redone).
- * Written as the tile loop's own row code is -- three records of a pixel on their way before the first is used, the guards'
- * lane masks ORed in scalar registers and pinned after every pixel: left alone, the compiler keeps every pixel's operands
- * alive to the end of the tile, and the loop that calls this spilled a quarter of its registers. */
-template <int OUT_KIND, int MODE, int PIPE>
-__device__ __forceinline__ uint64_t tile_t1_flag(const pix_params &pp, const t1_sens &sn, const pq_rec1 *t1, const tile_in &v, tile_out &o)
-{
-    uint32_t sb[2], sr[2];
-    uint64_t redo_m = 0;
-#pragma unroll
-    for (int row = 0; row < 2; row++) {
-        const float(&gv)[4] = row ? v.g1 : v.g0;
-        const float(&bv)[4] = row ? v.b1 : v.b0;
-        const float(&rv)[4] = row ? v.r1 : v.r0;
-        uint32_t Y[4], Cb[4], Cr[4];
-#pragma unroll
-        for (int col = 0; col < 4; col++) {
-            const float Gn = norm1<PIPE>(pp, 0, gv[col]), Bn = norm1<PIPE>(pp, 1, bv[col]), Rn = norm1<PIPE>(pp, 2, rv[col]);
-            const pq_rec1 cg = pq_t1_fetch(Gn, t1), cb = pq_t1_fetch(Bn, t1), cr = pq_t1_fetch(Rn, t1);
-            __builtin_amdgcn_sched_barrier(0);
-            float mg, mb, mr;
-            const float g = pix_scale(pq_t1_eval_m(Gn, cg, &mg), pp.mulY, pp.addY);
-            const float b = pix_scale(pq_t1_eval_m(Bn, cb, &mb), pp.mulC, pp.addC);
-            const float r = pix_scale(pq_t1_eval_m(Rn, cr, &mr), pp.mulC, pp.addC);
-            bool ra, rb;
-            pix_matrix_t1<MODE>(pp, sn, g, b, r, pq_t1_unsure3(mg, mb, mr), Y[col], Cb[col], Cr[col], &ra, &rb);
-            redo_m |= __builtin_amdgcn_ballot_w64(ra) | __builtin_amdgcn_ballot_w64(rb);
-            asm volatile("" : "+s"(redo_m));
-        }
-        row_pack<OUT_KIND, true, true>(pp, row, Y, Cb, Cr, o, sb, sr);
-    }
-    return redo_m;
-}
-
-/* one tile per lane out of the wave's list: entries [first, first + cnt).
- * What costs here is not the arithmetic but the scattered stores (partial lines of bytes long evicted
- * from the caches: measured 1.1 of the 1.9 us per 4K frame the passes took, the six loads 0.45, the
- * arithmetic 0.1), and most redone tiles come out as the first tier left them (an unsure sample is the
- * right float half of the time, a sensitive pixel rarely moves): the pass recomputes the first tier's
- * bytes and stores only the parts that differ. */
+/* one tile per lane out of the wave's list: entries [first, first + cnt).  (Until round 3, when every tile the first tier could
+ * not settle came here -- one in 250 --, the pass recomputed the loop's bytes and stored only the parts that differed: scattered
+ * partial lines were what it cost.  Now one tile in tens of thousands comes, and is stored whole.) */
 template <int IN_KIND, int OUT_KIND, int MODE, int PIPE>
 __device__ __forceinline__ void redo_pass(const redo_ctx *rc, const pix_params *spp, const pq_recA *sA, const uint32_t *list,
                                                     uint32_t first, uint32_t cnt)
@@ -780,13 +694,7 @@ __device__ __forceinline__ void redo_pass(const redo_ctx *rc, const pix_params *
     }
     tile_out o;
     tile_exact<OUT_KIND, MODE, PIPE>(*spp, spp, sA, sB, v, o);
-#if defined(H2Y_REDO_STOREALL) /* timing experiments only */
     tile_store<OUT_KIND>(io, t, rc->width, rc->height, o);
-#else
-    tile_out p;
-    tile_t1<OUT_KIND, MODE, PIPE>(*spp, rc->sn, rc->t1, v, p);
-    tile_store_changes<OUT_KIND>(io, t, rc->width, rc->height, o, p);
-#endif
 }
 
 #ifdef H2Y_BLOCK_TIMES /* timing experiments only: when does each block start its first tile and finish its last? */
@@ -834,8 +742,6 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
     if (threadIdx.x == 0) {
         s_pp = pp;
         s_rc.frames = a.frames;
-        s_rc.t1 = s_t1;
-        s_rc.sn = a.sn;
         s_rc.low_flag = a.low_flag;
         s_rc.width = a.width; s_rc.height = a.height; s_rc.wq = a.wq; s_rc.wq_magic = a.wq_magic;
         s_rc.tiles_per_frame = a.tiles_per_frame; s_rc.tiles_magic = a.tiles_magic;
@@ -860,6 +766,7 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
     block_clock_start(a);
     const uint32_t W = a.width, H = a.height;
     const uint32_t lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    const pq_recB *const sB2 = reinterpret_cast<const pq_recB *>(s_t2 + H2Y_PQ_NREC);
     uint32_t *const my_list = s_redo[wave];
     uint32_t n_redo = 0; /* entries in my_list (uniform over the wave) */
     /*
@@ -963,7 +870,8 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
         mm6 mm;
         mm.reset();
         const uint32_t id_base = (uint32_t)f * a.tiles_per_frame;
-        uint32_t flagged_f = 0; /* tiles of this frame this wave sent to the list (the host steers by their share) */
+        uint32_t flagged_f = 0;  /* tiles of this frame this wave sent to the list */
+        uint32_t flagged_px = 0; /* pixels of this frame the wave's lanes sent through the binary64 tier in the loop (the host steers by their share, in tiles of eight) */
         wave_deal deal, deal_n;
         if (ranged) {
             deal.set_range(r_first, r_count);
@@ -1116,7 +1024,45 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
                         const float r = pix_scale(pq_t1_eval_m(Rn, cr, &mr), pp.mulC, pp.addC);
                         bool ra, rb;
                         pix_matrix_t1<MODE>(pp, sn, g, b, r, pq_t1_unsure3(mg, mb, mr), Y[col], Cb[col], Cr[col], &ra, &rb);
-                        redo_m |= __builtin_amdgcn_ballot_w64(ra) | __builtin_amdgcn_ballot_w64(rb); /* a ballot of a compare is the compare's own result */
+                        const uint64_t fm = __builtin_amdgcn_ballot_w64(ra) | __builtin_amdgcn_ballot_w64(rb); /* a ballot of a compare is the compare's own result */
+                        if (__builtin_expect(fm != 0, 0)) {
+                            /* Some lane's pixel here is not settled (one wave-pixel in 25 on the headline's picture): the binary64
+                             * tier for this pixel position on the spot, as in k_fir_fused -- no global memory operation in the
+                             * branch, only LDS reads and, for samples below the tables, scalar loads; only the planes that hold an
+                             * unsure sample of a flagged lane go through it.  What it cannot settle either (a value too close to a
+                             * rounding tie for binary64, a NaN, the division guard: one pixel in tens of thousands) sends the
+                             * tile to the list.  Rounds 1-2 listed every such tile: on dark pictures one tile in 70. */
+                            const bool fl = ((fm >> lane) & 1u) != 0;
+                            const bool ug = pq_t1_unsure(mg), ub = pq_t1_unsure(mb), ur = pq_t1_unsure(mr);
+                            float g2 = g, b2 = b, r2 = r;
+                            bool un = false;
+                            if (__builtin_amdgcn_ballot_w64(fl & ug) != 0) {
+                                bool sl;
+                                const float t = pq_ext_inline(Gn, pq_fast(Gn, s_t2, sB2, &sl), sl, pp.pq_ext);
+                                g2 = (fl & ug) ? pix_scale(t, pp.mulY, pp.addY) : g2;
+                                un |= fl & ug & sl;
+                            }
+                            if (__builtin_amdgcn_ballot_w64(fl & ub) != 0) {
+                                bool sl;
+                                const float t = pq_ext_inline(Bn, pq_fast(Bn, s_t2, sB2, &sl), sl, pp.pq_ext);
+                                b2 = (fl & ub) ? pix_scale(t, pp.mulC, pp.addC) : b2;
+                                un |= fl & ub & sl;
+                            }
+                            if (__builtin_amdgcn_ballot_w64(fl & ur) != 0) {
+                                bool sl;
+                                const float t = pq_ext_inline(Rn, pq_fast(Rn, s_t2, sB2, &sl), sl, pp.pq_ext);
+                                r2 = (fl & ur) ? pix_scale(t, pp.mulC, pp.addC) : r2;
+                                un |= fl & ur & sl;
+                            }
+                            uint32_t Y2, Cb2, Cr2;
+                            bool um;
+                            pix_matrix<MODE, false>(pp, g2, b2, r2, Y2, Cb2, Cr2, &um);
+                            Y[col] = fl ? Y2 : Y[col];
+                            Cb[col] = fl ? Cb2 - pp.half_m1 : Cb[col]; /* raw, as the first tier's */
+                            Cr[col] = fl ? Cr2 - pp.half_m1 : Cr[col];
+                            redo_m |= __builtin_amdgcn_ballot_w64(fl & (un | um));
+                            flagged_px += (uint32_t)__popcll(fm);
+                        }
                         /* pin the mask here: left alone, the compiler postpones every pixel's guard arithmetic
                          * to the end of the tile and keeps its operands alive until then (register spills) */
                         asm volatile("" : "+s"(redo_m));
@@ -1154,7 +1100,7 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
             }
         }
         wave_store_mm(mm, a.partial + walk_slot(fw, H2Y_T1_THREADS / WAVE) * 6);
-        if (a.redo_count && lane == 0) a.redo_count[walk_slot(fw, H2Y_T1_THREADS / WAVE)] = flagged_f;
+        if (a.redo_count && lane == 0) a.redo_count[walk_slot(fw, H2Y_T1_THREADS / WAVE)] = flagged_f + (flagged_px >> 3);
     }
 #ifdef H2Y_BLOCK_TIMES /* blocks 0..3: when each wave left the frame loop */
     if (blockIdx.x < 4 && lane == 0) g_block_times[2 * (800 + blockIdx.x * 16 + wave)] = wall_clock64();

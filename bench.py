@@ -79,7 +79,7 @@ def parse(argv=None):
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE", help="h2y_ctx_set_option knobs (A/B timing), e.g. fir=twopass")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="process-group backend (nccl = RCCL; gloo only to rehearse N > 1)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0 (needs --backend gloo)")
-    ap.add_argument("--content", default="uniform", choices=["uniform", "bars", "squared"],
+    ap.add_argument("--content", default="uniform", choices=["uniform", "bars", "squared", "pow3", "pow4", "pow6"],
                     help="synthetic picture content (fp32 workloads): uniform = the SURVEY 8c generator (the headline; md5-checked); bars = the same "
                          "with the top and bottom 12.8 %% of the rows exactly zero (a 2.39:1 picture letterboxed in 16:9); squared = every sample "
                          "squared (darker).  Not md5-checked; implies --no-extra")
@@ -500,6 +500,8 @@ def main() -> int:
             for p in fr:
                 if args.content == "squared":
                     p.mul_(p)
+                elif args.content.startswith("pow"):  # darker still: 0.4 % / 1.6 % / 6 % of the samples below the kernels' tables
+                    p.pow_(int(args.content[3:]))
                 else:
                     p[: bar * w] = 0.0
                     p[(hh - bar) * w:] = 0.0

@@ -55,7 +55,11 @@ clip_limits make_clip(int bit_depth, int full_range)
 
 const int kMaxEvents = 64;
 const size_t kRangeWords = 1025; /* a table of slice ranges: up to 1024 blocks of a group + 1 */
-const double kT1DenseShare = 0.08; /* T1 costs ~1.6x more per redone tile, k_fused2 ~1.12x overall: break-even near 8 % */
+/* Share of a batch's pixels (counted in tiles of eight) the first tier passed on, above which the next batches go to the binary64
+ * tier's kernels.  Both first-tier kernels now take that tier inside their loops, a wave at a time: with 0.1-0.2 % of the pixels
+ * passed on they are 11-16 % ahead of the binary64 tier's kernels, with 1.3-1.5 % 8-19 % behind (tools/densebench.sh: u^2 and u^3
+ * of the uniform picture); the lines cross near 0.7 %.  (Rounds 1-2: 8 % -- of tiles, one unsettled pixel making a tile.) */
+const double kT1DenseShare = 0.007;
 /* A probe of the first tier on dense content is dear (letterboxed 4K, a quarter of the tiles flagged: 8.6 ms per 64-frame launch
  * against k_fused2's 1.6), staying on the binary64 tier too long is cheap (2-10 % slower than the first tier on content that
  * suits it): probe rarely -- after 32 batches, then 64, ... 1024. */
@@ -155,6 +159,7 @@ struct h2y_ctx {
     bool cur_skip_t1 = false;
     /* h2y_ctx_set_option(): tuning / test knobs, per context (nothing is read from the environment) */
     bool opt_t1 = true;        /* "t1": binary32 first tier on */
+    bool opt_t1_steer = true;  /* ... and left for the binary64 tier's kernels while the pictures keep it busy passing pixels on */
     int opt_groups = 0;        /* "groups": at most this many frame groups (power of two; 1 = off); 0 = by the frame's size (groups_cap()) */
     bool opt_cols8 = true;     /* "cols8": 8-column tiles for half input where the planes allow */
     int opt_bal_mode = 0;      /* "balance": 0 adaptive, 1 off, 2 fixed */
@@ -386,7 +391,7 @@ void t1_end_batch(h2y_ctx *ctx, const h2y_desc *d, const frame_stats *fs, int n)
         snprintf(note, sizeof note, " flagged=%.5f", tiles ? (double)redone / (double)tiles : 0.0);
         ctx->last_variant += note;
     }
-    if ((double)redone > kT1DenseShare * (double)tiles) {
+    if (ctx->opt_t1_steer && (double)redone > kT1DenseShare * (double)tiles) {
         /* still dense at the next probe: stay away twice as long */
         ctx->t1_skip_len = ctx->t1_skip_len ? (ctx->t1_skip_len < kT1SkipBatchesMax ? 2 * ctx->t1_skip_len : kT1SkipBatchesMax) : kT1SkipBatches;
         ctx->t1_skip = ctx->t1_skip_len;
@@ -1238,7 +1243,10 @@ int h2y_ctx_set_option(h2y_ctx *ctx, const char *name, const char *value)
     if (!ctx) return fail(nullptr, H2Y_EINVAL, "null ctx");
     if (!name || !value) return fail(ctx, H2Y_EINVAL, "null option name or value");
     if ((ctx->q_count > 0) || ctx->streaming) return fail(ctx, H2Y_EINVAL, "a batch is pending or a stream is open");
-    if (!strcmp(name, "t1")) ctx->opt_t1 = value[0] != '0';
+    if (!strcmp(name, "t1")) {
+        ctx->opt_t1 = value[0] != '0';
+        ctx->opt_t1_steer = strcmp(value, "always") != 0; /* "always": stay on the first tier however many pixels it passes on (timing) */
+    }
     else if (!strcmp(name, "cols8")) ctx->opt_cols8 = value[0] != '0';
     else if (!strcmp(name, "firsync")) {
         int v = atoi(value), p = 1;

@@ -62,4 +62,5 @@ PY
 # pictures unlike the headline's; transfer pairs at 8 frames per launch; the stream pipeline
 bash tools/contentbench.sh "$OUT/content" > "$OUT/content.txt" 2>&1
 python3 tools/tfbench.py > "$OUT/tfbench.txt" 2>&1
+bash tools/densebench.sh "$OUT/dense" > "$OUT/dense.txt" 2>&1
 python3 tools/streambench.py > "$OUT/streambench.txt" 2>&1

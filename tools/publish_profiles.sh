@@ -11,5 +11,5 @@ for n in c2box c2fir c3 c4 c4fir c1; do
   f=$(ls -t $S/$n/trace/*/*kernel_stats.csv | head -1)  # the newest: gpurun merges into what earlier calls left
   cp "$f" profiles/${R}_${n}_kernel_stats.csv
 done
-for f in tfbench.txt streambench.txt bench_c5_single_gpu.json content.txt layout.txt groups.txt firsync.txt fir_floor.txt blocktimes.txt tail_ab.txt; do [ -f $S/$f ] && cp $S/$f profiles/${R}_$f; done
+for f in tfbench.txt dense.txt streambench.txt bench_c5_single_gpu.json content.txt layout.txt groups.txt firsync.txt fir_floor.txt blocktimes.txt tail_ab.txt; do [ -f $S/$f ] && cp $S/$f profiles/${R}_$f; done
 ls -la profiles/ | grep $R

@@ -120,7 +120,7 @@ void h2y_ctx_destroy(h2y_ctx *ctx);
 const char *h2y_last_error(const h2y_ctx *ctx); /* ctx may be NULL: global error */
 
 /* Tuning and test knobs of one context, as strings (the library reads nothing from the environment):
- *   "t1" "0"|"1" (binary32 first tier), "groups" "0"|"1".."64" (frame groups; 0: by the frame's size), "cols8" "0"|"1"
+ *   "t1" "0"|"1"|"always" (binary32 first tier; "always": never steered away from it), "groups" "0"|"1".."64" (frame groups; 0: by the frame's size), "cols8" "0"|"1"
  *   (8-column tiles for half input), "balance" "adaptive"|"xcd"|"off"|"<xcd mask>,<ratio>" (slices by measured block / XCD speed),
  *   "tail" "auto"|"on"|"off" (the last frame of a frame group dealt dynamically), "fir" "auto"|"twopass"|"fused" (how chroma_resampler_type != 0 runs), "firsync" "auto"|"0".."1024" (the one-pass
  *   FIR kernel's waves meet at a barrier every so many steps).  None changes a byte of output.

@@ -1337,7 +1337,7 @@ inline bool t1_bounds(const pix_params &pp, t1_sens *sn)
 {
     const double u23 = 0x1p-23;
     if (!t1_chroma_in_range(pp)) return false;
-    const double sY = (double)pp.mulY * 1.2 + pp.addY, sC = (double)pp.mulC * 1.2 + pp.addC; /* PQ < 1.2 on the table's domain */
+    const double sY = (double)pp.mulY * 1.0005 + pp.addY, sC = (double)pp.mulC * 1.0005 + pp.addC; /* PQ <= PQ(1 + 2^-8) = 1.000408 for every sample the first tier answers (H2Y_T1_DOMAIN_HI) */
     const double smax = sY > sC ? sY : sC;
     double Ey, Ecb, Ecr;
     if (pp.mode == H2Y_MODE_YCBCR) {

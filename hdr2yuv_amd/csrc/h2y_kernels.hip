@@ -795,6 +795,8 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
     bool hold = false; /* (have implies hold: v is tick's tile; a redo pass drops the data, not the slice) */
     uint32_t dyn_carry = 0, dyn_t0_next = 0; /* the dynamic frame: first tile of a slice drawn from the frame before it / of the slice asked for */
     walk_init(fw, a);
+    typedef const __attribute__((address_space(4))) fused_args *args_ptr;
+    args_ptr ap = (args_ptr)__builtin_amdgcn_kernarg_segment_ptr();
     const uint32_t grp = (uint32_t)fw.f; /* the block's group: its first frame */
     uint32_t r_first, r_count;
     const bool ranged = block_range(a, fw, r_first, r_count);
@@ -865,8 +867,13 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
         const bool dyn = tail_ctr != nullptr && !fw.has_next();                         /* this frame is the group's dynamic one */
         const bool dyn_n = tail_ctr != nullptr && fw.has_next() && f + 2 * (int)fw.NG >= fw.n_frames; /* the next one is */
         uint32_t dyn_t0 = 0; /* dyn: first tile of the slice in hand / asked for */
-        const frame_io io = uniform_io(a.frames + f);
-        const frame_io io_next = uniform_io(a.frames + (fw.has_next() ? f + (int)fw.NG : f)); /* for the prefetch across the frame boundary */
+        asm volatile("" : "+s"(ap)); /* (what only a frame's beginning and end need is read there, through a pointer the compiler cannot see through: k_fir_fused, "scalar registers") */
+        const frame_io *const frames = ap->frames;
+        const frame_io io = uniform_io(frames + f);
+        /* the frame after this one in the group, for the prefetch across the frame boundary: its plane pointers are read when a wave
+         * gets there (scalar loads: the array is written before the launch), not kept in six scalar registers all frame long */
+        typedef const __attribute__((address_space(4))) frame_io *frame_cptr;
+        const frame_cptr io_next_p = (frame_cptr)(uintptr_t)(frames + (fw.has_next() ? f + (int)fw.NG : f));
         mm6 mm;
         mm.reset();
         const uint32_t id_base = (uint32_t)f * a.tiles_per_frame;
@@ -947,9 +954,19 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
                                 tt2 = nextf ? t0n : deal.tile0<H2Y_T1_THREADS>(tick);
                             }
                             }
+                            /* uniform values, and known to be: the dynamic frame's branch reads them out of LDS, after which the compiler
+                             * kept all three in vector registers and chose the plane pointers with vector selects (thirty
+                             * instructions a tile) */
+                            kind = __builtin_amdgcn_readfirstlane(kind);
+                            tick2 = __builtin_amdgcn_readfirstlane(tick2);
+                            tt2 = __builtin_amdgcn_readfirstlane(tt2);
                             hold = have = kind != 0;
 #pragma unroll
-                            for (int c = 0; c < 3; c++) src[c] = kind == 2 ? io_next.in[c] : io.in[c];
+                            for (int c = 0; c < 3; c++) src[c] = io.in[c];
+                            if (__builtin_expect(kind == 2, 0)) {
+#pragma unroll
+                                for (int c = 0; c < 3; c++) src[c] = io_next_p->in[c];
+                            }
                             t2 = tile_locate(umin32(tt2 + lane, a.tiles_per_frame - 1u), W, H, a.wq, a.wq_magic);
                         }
                     IN::load4q(src[0], t2.q0, nx.g0);
@@ -1099,8 +1116,9 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
 #endif
             }
         }
-        wave_store_mm(mm, a.partial + walk_slot(fw, H2Y_T1_THREADS / WAVE) * 6);
-        if (a.redo_count && lane == 0) a.redo_count[walk_slot(fw, H2Y_T1_THREADS / WAVE)] = flagged_f + (flagged_px >> 3);
+        asm volatile("" : "+s"(ap));
+        wave_store_mm(mm, ap->partial + walk_slot(fw, H2Y_T1_THREADS / WAVE) * 6);
+        if (ap->redo_count && lane == 0) ap->redo_count[walk_slot(fw, H2Y_T1_THREADS / WAVE)] = flagged_f + (flagged_px >> 3);
     }
 #ifdef H2Y_BLOCK_TIMES /* blocks 0..3: when each wave left the frame loop */
     if (blockIdx.x < 4 && lane == 0) g_block_times[2 * (800 + blockIdx.x * 16 + wave)] = wall_clock64();

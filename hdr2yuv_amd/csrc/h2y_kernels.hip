@@ -1101,8 +1101,8 @@ __global__ __launch_bounds__(H2Y_T1_THREADS) void k_fused_t1(fused_args a)
                     const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                     /* unflagged lanes write to the spare last slot: no branch in the loop body */
                     my_list[flagged ? n_redo + below : (uint32_t)(H2Y_REDO_CAP - 1)] = id_base + umin32(tt, a.tiles_per_frame - 1u);
-                    n_redo += (uint32_t)__popcll(m);
-                    flagged_f += (uint32_t)__popcll(m);
+                    n_redo = __builtin_amdgcn_readfirstlane(n_redo + (uint32_t)__popcll(m)); /* (uniform, and said to be: the loop's exit test stays a scalar one) */
+                    flagged_f = __builtin_amdgcn_readfirstlane(flagged_f + (uint32_t)__popcll(m));
                 }
                 more = kind == 1;
                 tick = tick2;

@@ -88,7 +88,11 @@ __device__ __forceinline__ int32_t dot2(uint32_t v, uint32_t k, int32_t acc)
  * minus (Half - 1).  The taps sum to 512, so the offset is one constant in the stage's rounding term: k0 = 512 (Half - 1)
  * + 256 (without RAWC: 256).  a and b come out as code values either way. */
 template <bool RAWC>
-__device__ __forceinline__ uint32_t ff_pack16(uint32_t lo, uint32_t hi) { return RAWC ? ((lo & 0xFFFFu) | (hi << 16)) : (lo | (hi << 16)); }
+__device__ __forceinline__ uint32_t ff_pack16(uint32_t lo, uint32_t hi)
+{
+    /* low halves of both: one v_perm_b32 (bytes 1, 0 of hi over bytes 1, 0 of lo); written as and / shift / or it came out as two instructions */
+    return RAWC ? __builtin_amdgcn_perm(hi, lo, 0x05040100u) : (lo | (hi << 16));
+}
 template <bool RAWC>
 __device__ __forceinline__ void ff_hstage(const uint32_t (&c)[4], const ff_edges &e, int32_t maxcv, uint32_t k0, uint32_t &a, uint32_t &b)
 {

@@ -67,7 +67,9 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=10)  # the card clocks up during the first ~10 launches
-    ap.add_argument("--frames", type=int, default=64, help="frames per GPU per step (64 x 124 MB = 8 GB of the 288)")
+    ap.add_argument("--frames", type=int, default=128, help="frames per GPU per step (128 x 124 MB = 16 GB of the 288; one launch: the library splits "
+                    "longer batches.  Rounds 1-3 measured 64: a launch's fixed costs -- tables staged per block, the blocks' finish spread, "
+                    "the FIR path's row segments -- weigh half as much at 128: box +0.5 % on the kernel and +1.2 % on value, FIR +1.5 % / +1.8 %)")
     ap.add_argument("--workload", default="C2", choices=sorted(WORKLOADS))
     ap.add_argument("--resampler", default="box", choices=["box", "fir"])
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -598,11 +598,13 @@ def main() -> int:
         plan = []
         if is420:
             plan.append((args.workload, "fir" if args.resampler == "box" else "box", F))
-        for wl, nf in (("C3", 64), ("C1", 64), ("C4", 16)):
+        # frames per launch of the passes beside the headline: what a launch pays once weighs less in a longer one (C3 64 -> 128 frames
+        # +0.9 %, C1 64 -> 256 small frames +9 %, C4 FIR 16 -> 32 +3 %; C4 box is no faster at 32: tools/framesweep2.sh)
+        for wl, nf in (("C3", 128), ("C1", 256), ("C4", 16)):
             if wl != args.workload:
                 plan.append((wl, "box", nf))
         if args.workload != "C4":
-            plan.append(("C4", "fir", 16))
+            plan.append(("C4", "fir", 32))
         if args.workload == "C2":
             for name in TF_PAIRS:
                 plan.append((name, "box", F))

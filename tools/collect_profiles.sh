@@ -23,8 +23,8 @@ prof c2box
 prof c2fir --resampler fir
 prof c3 --workload C3
 prof c4 --workload C4 --frames 16
-prof c4fir --workload C4 --frames 16 --resampler fir
-prof c1 --workload C1
+prof c4fir --workload C4 --frames 32 --resampler fir
+prof c1 --workload C1 --frames 256
 python3 - "$OUT" <<'PY'
 import hashlib, json, os, re, sys
 out = sys.argv[1]
@@ -36,9 +36,9 @@ spec.loader.exec_module(bench)
 res = {"_how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, tools/prof.sh) on `python3 bench.py --no-extra --no-cpu-baseline ...`; "
                "per-dispatch average of the dominant kernel; FETCH_SIZE doubled (MI355X_MICROARCH.md: gfx950 reports half the bytes of wide coalesced "
                "16-B/lane reads), both in KiB", "library_sha256": sha, "sources_sha256": bench.sources_sha256()}
-F = 128  # bench.py's default frames per step (C4: 16, given on the command lines above)
+F = 128  # bench.py's default frames per step (C4 box 16, C4 FIR 32, C1 256: given on the command lines above, as bench.py's `others` run them)
 alg = {"c2box": (f"C2_box_F{F}", 15.0 * 3840 * 2160 * F), "c2fir": (f"C2_fir_F{F}", 15.0 * 3840 * 2160 * F), "c3": (f"C3_box_F{F}", 18.0 * 3840 * 2160 * F),
-       "c4": ("C4_box_F16", 9.0 * 7680 * 4320 * 16), "c4fir": ("C4_fir_F16", 9.0 * 7680 * 4320 * 16), "c1": (f"C1_box_F{F}", 15.0 * 1920 * 1080 * F)}
+       "c4": ("C4_box_F16", 9.0 * 7680 * 4320 * 16), "c4fir": ("C4_fir_F32", 9.0 * 7680 * 4320 * 32), "c1": ("C1_box_F256", 15.0 * 1920 * 1080 * 256)}
 for name, (key, ab) in alg.items():
     try:
         txt = open(os.path.join(out, f"summary_{name}.txt")).read()
